@@ -1,0 +1,689 @@
+/*
+ * ofdm_oracle.c -- CPU (f64) restatement of the jkelleyrtp/ofdm TX/RX hot path.
+ * TEST INFRASTRUCTURE ONLY -- see ofdm_oracle.h for the rules and the pinning status.
+ *
+ * Plain C99, no dependencies beyond libm.  Arithmetic follows the reference line by line where the
+ * reference has code (citations in ofdm_oracle.h and at each function); where it relies on a crate that
+ * is not under /root/reference (rustfft 6, num 0.3 Complex64, bincode 1.3) the crate's published
+ * contract is restated: unnormalised forward DFT, naive complex mul/div, exp via from_polar,
+ * fixint little-endian u128 header.
+ */
+#include "ofdm_oracle.h"
+
+#include <complex.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ num::Complex64 arithmetic */
+static inline oc64 c_new(double re, double im) { oc64 z = {re, im}; return z; }
+static inline oc64 c_add(oc64 a, oc64 b) { return c_new(a.re + b.re, a.im + b.im); }
+static inline oc64 c_sub(oc64 a, oc64 b) { return c_new(a.re - b.re, a.im - b.im); }
+static inline oc64 c_mul(oc64 a, oc64 b) { return c_new(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+static inline oc64 c_conj(oc64 a) { return c_new(a.re, -a.im); }
+static inline double c_norm_sqr(oc64 a) { return a.re * a.re + a.im * a.im; }
+/* num-complex Div: naive (non-Smith) form */
+static inline oc64 c_div(oc64 a, oc64 b) {
+    double ns = b.re * b.re + b.im * b.im;
+    return c_new((a.re * b.re + a.im * b.im) / ns, (a.im * b.re - a.re * b.im) / ns);
+}
+static inline oc64 c_scale(oc64 a, double s) { return c_new(a.re * s, a.im * s); }
+/* num-complex exp: from_polar(exp(re), im) */
+static inline oc64 c_exp(oc64 a) {
+    double r = exp(a.re);
+    return c_new(r * cos(a.im), r * sin(a.im));
+}
+
+/* ------------------------------------------------------------------ PRNG (documented; NOT rand::StdRng) */
+uint64_t orc_splitmix64(uint64_t *state) {
+    uint64_t z = (*state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+double orc_uniform_01(uint64_t *state) { return (double)(orc_splitmix64(state) >> 11) * (1.0 / 9007199254740992.0); }
+double orc_uniform_pm1(uint64_t *state) { return orc_uniform_01(state) * 2.0 - 1.0; }
+
+/* ------------------------------------------------------------------ FFT (rustfft contract: unnormalised DFT) */
+static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+static void fft_pow2(oc64 *x, int n, int inverse) {
+    /* iterative radix-2 DIT, twiddles from libm per stage index (no recurrence, keeps 1e-15 accuracy) */
+    for (int i = 1, j = 0; i < n; i++) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { oc64 t = x[i]; x[i] = x[j]; x[j] = t; }
+    }
+    double sgn = inverse ? 1.0 : -1.0;
+    for (int len = 2; len <= n; len <<= 1) {
+        int half = len >> 1;
+        for (int k = 0; k < half; k++) {
+            double ang = sgn * 2.0 * M_PI * (double)k / (double)len;
+            oc64 w = c_new(cos(ang), sin(ang));
+            for (int i = k; i < n; i += len) {
+                oc64 u = x[i], v = c_mul(x[i + half], w);
+                x[i] = c_add(u, v);
+                x[i + half] = c_sub(u, v);
+            }
+        }
+    }
+}
+
+static void fft_bluestein(oc64 *x, int n, int inverse) {
+    int m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    oc64 *w = (oc64 *)malloc(sizeof(oc64) * (size_t)n);
+    oc64 *a = (oc64 *)calloc((size_t)m, sizeof(oc64));
+    oc64 *b = (oc64 *)calloc((size_t)m, sizeof(oc64));
+    double sgn = inverse ? 1.0 : -1.0;
+    for (int i = 0; i < n; i++) {
+        long long sq = ((long long)i * (long long)i) % (2LL * n); /* exact reduction of i^2 mod 2n */
+        double ang = sgn * M_PI * (double)sq / (double)n;
+        w[i] = c_new(cos(ang), sin(ang));
+    }
+    for (int i = 0; i < n; i++) a[i] = c_mul(x[i], w[i]);
+    b[0] = c_conj(w[0]);
+    for (int i = 1; i < n; i++) b[i] = b[m - i] = c_conj(w[i]);
+    fft_pow2(a, m, 0);
+    fft_pow2(b, m, 0);
+    for (int i = 0; i < m; i++) a[i] = c_mul(a[i], b[i]);
+    fft_pow2(a, m, 1);
+    for (int i = 0; i < n; i++) x[i] = c_mul(c_scale(a[i], 1.0 / (double)m), w[i]);
+    free(w); free(a); free(b);
+}
+
+/* signals/mod.rs:27-58: fft = unnormalised forward; ifft = unnormalised inverse then normalize_by(1/len) */
+void orc_fft(oc64 *x, int n, int inverse) {
+    if (n <= 1) return;
+    if (is_pow2(n)) fft_pow2(x, n, inverse);
+    else fft_bluestein(x, n, inverse);
+    if (inverse) {
+        double s = 1.0 / (double)n;
+        for (int i = 0; i < n; i++) x[i] = c_scale(x[i], s); /* normalize_by: *val *= scale (mod.rs:132-138) */
+    }
+}
+
+static void rotate_left(oc64 *x, int n, int mid) {
+    oc64 *t = (oc64 *)malloc(sizeof(oc64) * (size_t)n);
+    memcpy(t, x, sizeof(oc64) * (size_t)n);
+    for (int i = 0; i < n; i++) x[i] = t[(i + mid) % n]; /* r.iter().chain(l.iter()) */
+    free(t);
+}
+void orc_fft_shift(oc64 *x, int n) { if (n > 0) rotate_left(x, n, (n + 1) / 2); }  /* mod.rs:65: mid=floor((len+1)/2) */
+void orc_ifft_shift(oc64 *x, int n) { if (n > 0) rotate_left(x, n, n / 2); }       /* mod.rs:84: mid=floor(len/2) */
+
+/* signals/mod.rs:186-217 */
+int orc_xcorr_fft(const oc64 *a_in, int na, const oc64 *b_in, int nb, oc64 *out) {
+    int pad = 2 * na - 1;
+    oc64 *a = out;
+    oc64 *b = (oc64 *)calloc((size_t)pad, sizeof(oc64));
+    memset(a, 0, sizeof(oc64) * (size_t)pad);
+    memcpy(a, a_in, sizeof(oc64) * (size_t)na);
+    memcpy(b, b_in, sizeof(oc64) * (size_t)(nb < pad ? nb : pad));
+    orc_fft(a, pad, 0);
+    orc_fft(b, pad, 0);
+    for (int i = 0; i < pad; i++) a[i] = c_mul(a[i], c_conj(b[i]));
+    orc_fft(a, pad, 1);
+    orc_fft_shift(a, pad);
+    free(b);
+    double max = 0.0; /* Complex64::default().norm_sqr() */
+    int idx_max = 0;
+    for (int i = 0; i < pad; i++) {
+        double v = c_norm_sqr(a[i]);
+        if (v > max) { idx_max = i; max = v; }
+    }
+    return idx_max;
+}
+
+/* signals/mod.rs:219-237 */
+void orc_convolve(const oc64 *a_in, int na, const oc64 *b_in, int nb, oc64 *out) {
+    int pad = na + nb - 1;
+    oc64 *b = (oc64 *)calloc((size_t)pad, sizeof(oc64));
+    memset(out, 0, sizeof(oc64) * (size_t)pad);
+    memcpy(out, a_in, sizeof(oc64) * (size_t)na);
+    memcpy(b, b_in, sizeof(oc64) * (size_t)nb);
+    orc_fft(out, pad, 0);
+    orc_fft(b, pad, 0);
+    for (int i = 0; i < pad; i++) out[i] = c_mul(out[i], b[i]);
+    orc_fft(out, pad, 1);
+    free(b);
+}
+
+/* signals/mod.rs:251-259 */
+oc64 orc_mean(const oc64 *x, int n) {
+    oc64 s = c_new(0, 0);
+    for (int i = 0; i < n; i++) s = c_add(s, x[i]);
+    s.re /= (double)n;
+    s.im /= (double)n;
+    return s;
+}
+/* signals/mod.rs:239-249: sum((mean - x)^2)/len, complex square, NOT conjugated */
+oc64 orc_variance(const oc64 *x, int n) {
+    oc64 m = orc_mean(x, n), s = c_new(0, 0);
+    for (int i = 0; i < n; i++) {
+        oc64 d = c_sub(m, x[i]);
+        s = c_add(s, c_mul(d, d));
+    }
+    return c_new(s.re / (double)n, s.im / (double)n);
+}
+/* receiver.rs:242-246 */
+double orc_angle(oc64 z) { return atan2(z.im, z.re); }
+
+/* ------------------------------------------------------------------ utils.rs */
+void orc_to_bools(uint8_t b, uint8_t out[8]) { for (int i = 0; i < 8; i++) out[i] = (b & (1u << i)) != 0; }
+uint8_t orc_bools_to_u8(const uint8_t in[8]) {
+    uint8_t o = 0;
+    for (int i = 0; i < 8; i++) o |= (uint8_t)((in[i] ? 1u : 0u) << i);
+    return o;
+}
+void orc_analysis(const uint8_t *l, const uint8_t *r, size_t n, uint32_t *num_errs, uint32_t *num_block_errs,
+                  double *err_rate) {
+    uint32_t e = 0, be = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (l[i] != r[i]) { e += (uint32_t)__builtin_popcount((unsigned)(l[i] ^ r[i])); be += 1; }
+    }
+    *num_errs = e;
+    *num_block_errs = be;
+    *err_rate = (double)e / ((double)n * 8.0);
+}
+void orc_sig_to_fc32(const oc64 *x, size_t n, float *out) {
+    for (size_t i = 0; i < n; i++) { out[2 * i] = (float)x[i].re; out[2 * i + 1] = (float)x[i].im; }
+}
+void orc_fc32_to_sig(const float *in, size_t n, oc64 *out) {
+    for (size_t i = 0; i < n; i++) out[i] = c_new((double)in[2 * i], (double)in[2 * i + 1]);
+}
+
+/* ------------------------------------------------------------------ carrier map */
+int orc_carrier_class(int bin, int n_fft, int guard) {
+    if (!guard) return 0;
+    int i = bin / (n_fft / 64); /* EXT-4: class of bin = reference class of floor(bin/k) */
+    if (i >= 59 || i <= 5 || i == 32) return 1;                 /* transmitter.rs:153 */
+    if (i == 6 || i == 25 || i == 39 || i == 58) return 2;      /* transmitter.rs:156 */
+    return 0;
+}
+int orc_data_carriers(int n_fft, int guard) { return guard ? 48 * (n_fft / 64) : n_fft; }
+
+/* ------------------------------------------------------------------ transmitter.rs */
+void orc_locking_signal(int len, oc64 *out) {
+    for (int i = 0; i < len; i++) out[i] = c_new(0.5 * ((double)i / (2.0 * (double)len) + 0.5), 0.0);
+    orc_fft_shift(out, len);
+}
+void orc_default_preamble(int len, oc64 *out) {
+    uint64_t st = 100;
+    for (int i = 0; i < len; i++) {
+        double re = orc_uniform_pm1(&st), im = orc_uniform_pm1(&st);
+        out[i] = c_scale(c_new(re, im), 0.25);
+    }
+}
+void orc_default_training(int len, oc64 *out) {
+    uint64_t st = 50;
+    for (int i = 0; i < len; i++) {
+        double re = orc_uniform_pm1(&st), im = orc_uniform_pm1(&st);
+        out[i] = c_scale(c_new(re, im), 1.0);
+    }
+}
+
+static inline int stream_bit(const uint8_t *bytes, size_t nbytes, size_t bit) {
+    size_t by = bit >> 3;
+    if (by >= nbytes) return 0;
+    return (bytes[by] >> (bit & 7)) & 1; /* LSB-first, utils.rs:21-27 */
+}
+static inline unsigned gray_decode(unsigned g) {
+    unsigned l = g;
+    for (unsigned s = g >> 1; s; s >>= 1) l ^= s;
+    return l;
+}
+/* EXT-1 per-axis level: first bit of the group is the Gray MSB (1 => positive half), levels in [-1,1] */
+static double axis_level(const int *bits, int m) {
+    unsigned g = 0;
+    for (int i = 0; i < m; i++) g = (g << 1) | (unsigned)bits[i];
+    unsigned l = gray_decode(g);
+    unsigned M = 1u << m;
+    return ((double)(2 * (int)l - (int)(M - 1))) / (double)(M - 1);
+}
+size_t orc_modulate_count(size_t nbytes, int modulation) {
+    return (nbytes * 8 + (size_t)modulation - 1) / (size_t)modulation;
+}
+/* transmitter.rs:108-140 (Bpsk, Qpsk) + EXT-1 (16/64/256-QAM) */
+size_t orc_modulate(const uint8_t *bytes, size_t nbytes, int modulation, oc64 *out) {
+    size_t nsym = orc_modulate_count(nbytes, modulation);
+    for (size_t s = 0; s < nsym; s++) {
+        int bits[8];
+        for (int j = 0; j < modulation; j++) bits[j] = stream_bit(bytes, nbytes, s * (size_t)modulation + (size_t)j);
+        if (modulation == ORC_BPSK) {
+            out[s] = c_new(bits[0] ? 1.0 : -1.0, 0.0);
+        } else {
+            int m = modulation / 2;
+            out[s] = c_new(axis_level(bits, m), axis_level(bits + m, m));
+        }
+    }
+    return nsym;
+}
+/* transmitter.rs:144-165 */
+void orc_encode_block(const oc64 *stream, size_t avail, size_t *consumed, int n_fft, int guard, oc64 *out) {
+    size_t used = 0;
+    for (int i = 0; i < n_fft; i++) {
+        int cls = orc_carrier_class(i, n_fft, guard);
+        if (cls == 1) out[i] = c_new(0.0, 0.0);
+        else if (cls == 2) out[i] = c_new(1.0, 0.0);
+        else if (used < avail) out[i] = stream[used++];
+        else out[i] = c_new(0.0, 0.0); /* unwrap_or_else(|| 0) */
+    }
+    *consumed = used;
+}
+/* transmitter.rs:168-181 */
+void orc_prefix_block(const oc64 *freq, int n_fft, int cp, oc64 *out) {
+    oc64 *t = (oc64 *)malloc(sizeof(oc64) * (size_t)n_fft);
+    memcpy(t, freq, sizeof(oc64) * (size_t)n_fft);
+    orc_fft(t, n_fft, 1);
+    memcpy(out, t + (n_fft - cp), sizeof(oc64) * (size_t)cp);
+    memcpy(out + cp, t, sizeof(oc64) * (size_t)n_fft);
+    free(t);
+}
+/* transmitter.rs:183-194: signed max over re and im, starting from 0 */
+void orc_normalize(oc64 *x, size_t n) {
+    double max = 0.0;
+    for (size_t i = 0; i < n; i++) { max = fmax(x[i].re, max); max = fmax(x[i].im, max); }
+    for (size_t i = 0; i < n; i++) { x[i].re = x[i].re / max; x[i].im = x[i].im / max; }
+}
+size_t orc_frame_len(size_t payload_bytes, int n_fft, int cp, int guard, int modulation) {
+    size_t S = (size_t)(n_fft + cp);
+    size_t nsym = orc_modulate_count(16 + payload_bytes, modulation);
+    size_t nd = (size_t)orc_data_carriers(n_fft, guard);
+    return 10 * S + S * ((nsym + nd - 1) / nd);
+}
+/* transmitter.rs:11-58.  Header + payload are modulated as ONE byte stream (identical to the reference's
+ * modulate(header).chain(modulate(data)) for BPSK/QPSK, where a byte is a whole number of symbols; required
+ * for 64-QAM so that the receiver's "drain 16 bytes" (receiver.rs:86-93) stays byte-aligned). */
+size_t orc_encode(const uint8_t *data, size_t nbytes, int n_fft, int cp, int guard, int modulation,
+                  const oc64 *preamble, const oc64 *training, oc64 *out) {
+    int S = n_fft + cp;
+    size_t pos = 0;
+    orc_locking_signal(S, out);
+    pos += (size_t)S;
+    for (int r = 0; r < 4; r++) { memcpy(out + pos, preamble, sizeof(oc64) * (size_t)S); pos += (size_t)S; }
+    for (int r = 0; r < 5; r++) { orc_prefix_block(training, n_fft, cp, out + pos); pos += (size_t)S; }
+
+    size_t tot = 16 + nbytes;
+    uint8_t *stream_bytes = (uint8_t *)malloc(tot);
+    memset(stream_bytes, 0, 16);
+    uint64_t len64 = (uint64_t)nbytes; /* bincode fixint LE u128 (packets/mod.rs:20-32) */
+    for (int i = 0; i < 8; i++) stream_bytes[i] = (uint8_t)(len64 >> (8 * i));
+    memcpy(stream_bytes + 16, data, nbytes);
+    size_t nsym = orc_modulate_count(tot, modulation);
+    oc64 *sym = (oc64 *)malloc(sizeof(oc64) * (nsym ? nsym : 1));
+    orc_modulate(stream_bytes, tot, modulation, sym);
+    oc64 *blk = (oc64 *)malloc(sizeof(oc64) * (size_t)n_fft);
+    size_t used = 0;
+    while (used < nsym) { /* while complex_stream.peek().is_some() */
+        size_t c = 0;
+        orc_encode_block(sym + used, nsym - used, &c, n_fft, guard, blk);
+        used += c;
+        orc_prefix_block(blk, n_fft, cp, out + pos);
+        pos += (size_t)S;
+    }
+    orc_normalize(out, pos);
+    free(blk); free(sym); free(stream_bytes);
+    return pos;
+}
+
+/* ------------------------------------------------------------------ receiver.rs */
+void orc_unprefix_block(const oc64 *in, int n_fft, int cp, oc64 *out) {
+    memcpy(out, in + cp, sizeof(oc64) * (size_t)n_fft);
+    orc_fft(out, n_fft, 0);
+}
+/* receiver.rs:106-145.  pilot_count is 4 in the reference (64 carriers); 4k for n_fft = 64k (EXT-4). */
+size_t orc_decode_block(const oc64 *in, int n_fft, int guard, oc64 *out) {
+    double pilot_count = 4.0 * (double)(n_fft / 64);
+    double phase = 0.0;
+    size_t cnt = 0;
+    for (int i = 0; i < n_fft; i++) {
+        int cls = orc_carrier_class(i, n_fft, guard);
+        if (cls == 1) continue;
+        if (cls == 2) { phase = phase + orc_angle(c_div(in[i], c_new(1.0, 0.0))); continue; }
+        out[cnt++] = in[i];
+    }
+    phase /= pilot_count;
+    oc64 rot = c_exp(c_scale(c_new(0.0, -1.0), phase));
+    for (size_t i = 0; i < cnt; i++) out[i] = c_mul(out[i], rot);
+    return cnt;
+}
+static unsigned axis_decide(double x, int m) {
+    unsigned M = 1u << m;
+    double u = x * (double)(M - 1);
+    if (!(u == u)) return 0; /* NaN */
+    double f = floor(u * 0.5) + (double)(M / 2);
+    if (f < 0.0) f = 0.0;
+    if (f > (double)(M - 1)) f = (double)(M - 1);
+    unsigned l = (unsigned)f;
+    return l ^ (l >> 1); /* Gray code, MSB = first stream bit */
+}
+static void symbol_bits(oc64 s, int modulation, int *bits) {
+    if (modulation == ORC_BPSK) {
+        bits[0] = s.re > 0.0; /* receiver.rs:162 */
+    } else if (modulation == ORC_QPSK) {
+        /* receiver.rs:169-175 match arms, in order (tie rules Q6) */
+        double re = s.re, im = s.im;
+        int l, r;
+        if (re >= 0.0 && im >= 0.0) { l = 1; r = 1; }
+        else if (re >= 0.0 && im <= 0.0) { l = 1; r = 0; }
+        else if (re < 0.0 && im > 0.0) { l = 0; r = 1; }
+        else if (re < 0.0 && im < 0.0) { l = 0; r = 0; }
+        else { l = 0; r = 0; }
+        bits[0] = l; bits[1] = r;
+    } else {
+        int m = modulation / 2;
+        unsigned gi = axis_decide(s.re, m), gq = axis_decide(s.im, m);
+        for (int i = 0; i < m; i++) {
+            bits[i] = (int)((gi >> (m - 1 - i)) & 1u);
+            bits[m + i] = (int)((gq >> (m - 1 - i)) & 1u);
+        }
+    }
+}
+void orc_demap_indices(const oc64 *sym, size_t nsym, int modulation, uint8_t *idx) {
+    for (size_t s = 0; s < nsym; s++) {
+        int bits[8];
+        symbol_bits(sym[s], modulation, bits);
+        unsigned v = 0;
+        for (int j = 0; j < modulation; j++) v |= (unsigned)bits[j] << j;
+        idx[s] = (uint8_t)v;
+    }
+}
+/* receiver.rs:147-190: 8 symbols per step, bits packed LSB-first; returns 0 if nsym % 8 != 0 (assert) */
+size_t orc_demodulate(const oc64 *sym, size_t nsym, int modulation, uint8_t *out) {
+    if (nsym % 8 != 0) return 0;
+    size_t nbytes = nsym * (size_t)modulation / 8;
+    memset(out, 0, nbytes);
+    for (size_t s = 0; s < nsym; s++) {
+        int bits[8];
+        symbol_bits(sym[s], modulation, bits);
+        for (int j = 0; j < modulation; j++) {
+            size_t b = s * (size_t)modulation + (size_t)j;
+            out[b >> 3] |= (uint8_t)(bits[j] << (b & 7));
+        }
+    }
+    return nbytes;
+}
+/* receiver.rs:212-229 */
+void orc_estimate_channel(const oc64 *blocks, int n_fft, int cp, const oc64 *training, oc64 *hk) {
+    int S = n_fft + cp;
+    oc64 *t = (oc64 *)malloc(sizeof(oc64) * (size_t)n_fft);
+    for (int i = 0; i < n_fft; i++) hk[i] = c_new(0, 0);
+    for (int b = 0; b < 5; b++) {
+        orc_unprefix_block(blocks + (size_t)b * (size_t)S, n_fft, cp, t);
+        for (int i = 0; i < n_fft; i++) hk[i] = c_add(hk[i], c_div(t[i], training[i]));
+    }
+    for (int i = 0; i < n_fft; i++) { hk[i].re /= 5.0; hk[i].im /= 5.0; }
+    free(t);
+}
+/* receiver.rs:231-240 (80 -> len) */
+double orc_frequency_correction(const oc64 *left, const oc64 *right, int len) {
+    double sum = 0.0;
+    for (int i = 0; i < len; i++) sum += orc_angle(c_div(right[i], left[i]));
+    return fabs((sum / (double)len) / (double)len);
+}
+/* receiver.rs:44-50 */
+void orc_cfo_rotate(oc64 *x, size_t n, double f_delta, size_t first_index) {
+    for (size_t i = 0; i < n; i++) {
+        oc64 e = c_scale(c_scale(c_new(0.0, -1.0), f_delta), (double)(first_index + i));
+        x[i] = c_mul(x[i], c_exp(e));
+    }
+}
+
+/* ------------------------------------------------------------------ EXT-3 Schmidl-Cox */
+static void sc_at(const oc64 *r, long d, int L, int W, oc64 *P, double *E, double *R) {
+    oc64 p = c_new(0, 0);
+    double e = 0, q = 0;
+    for (int m = 0; m < W; m++) {
+        oc64 a = r[d + m], b = r[d + m + L];
+        p = c_add(p, c_mul(c_conj(a), b));
+        e += c_norm_sqr(a);
+        q += c_norm_sqr(b);
+    }
+    *P = p; *E = e; *R = q;
+}
+int orc_sc_sync(const oc64 *r, size_t n, int L, int window_reps, long n_lags, double threshold, oc64 *p_hat,
+                double *metric, double *f_delta) {
+    int W = window_reps * L;
+    long valid = (long)n - (long)W - (long)L + 1;
+    if (n_lags <= 0 || n_lags > valid) n_lags = valid;
+    long best = -1, d1 = -1, last = n_lags;
+    double bnum = 0.0, bden = 1.0;
+    oc64 bp = c_new(0, 0);
+    for (long d = 0; d < n_lags && d <= last; d++) {
+        oc64 P; double E, R;
+        sc_at(r, d, L, W, &P, &E, &R);
+        double num = c_norm_sqr(P), den = E * R;
+        if (!(den > 0.0)) continue;
+        if (d1 < 0) {
+            if (!(num >= threshold * den)) continue; /* packet detect: first lag with M(d) >= threshold */
+            d1 = d;
+            last = d1 + (long)W; /* then the first maximum of M over [d1, d1 + W] */
+            best = d; bnum = num; bden = den; bp = P;
+            continue;
+        }
+        /* M(d) > M(best)  <=>  num * bden > bnum * den */
+        if (num * bden > bnum * den) { best = d; bnum = num; bden = den; bp = P; }
+    }
+    if (p_hat) *p_hat = bp;
+    if (metric) *metric = best >= 0 ? bnum / bden : 0.0;
+    if (f_delta) *f_delta = best >= 0 ? atan2(bp.im, bp.re) / (double)L : 0.0;
+    return (int)best;
+}
+void orc_sc_metric(const oc64 *r, size_t n, int L, int window_reps, long n_lags, double *metric, oc64 *p) {
+    int W = window_reps * L;
+    long valid = (long)n - (long)W - (long)L + 1;
+    if (n_lags <= 0 || n_lags > valid) n_lags = valid;
+    for (long d = 0; d < n_lags; d++) {
+        oc64 P; double E, R;
+        sc_at(r, d, L, W, &P, &E, &R);
+        double den = E * R;
+        metric[d] = den > 0.0 ? c_norm_sqr(P) / den : 0.0;
+        if (p) p[d] = P;
+    }
+}
+
+/* ------------------------------------------------------------------ EXT-2 Hamming(7,4) */
+static inline unsigned ham_enc_nibble(unsigned d) {
+    unsigned d0 = d & 1, d1 = (d >> 1) & 1, d2 = (d >> 2) & 1, d3 = (d >> 3) & 1;
+    unsigned p0 = d0 ^ d1 ^ d3, p1 = d0 ^ d2 ^ d3, p2 = d1 ^ d2 ^ d3;
+    return (d & 0xF) | (p0 << 4) | (p1 << 5) | (p2 << 6);
+}
+static inline unsigned ham_dec_word(unsigned c, unsigned *fixed) {
+    unsigned b0 = c & 1, b1 = (c >> 1) & 1, b2 = (c >> 2) & 1, b3 = (c >> 3) & 1;
+    unsigned s0 = ((c >> 4) & 1) ^ b0 ^ b1 ^ b3, s1 = ((c >> 5) & 1) ^ b0 ^ b2 ^ b3, s2 = ((c >> 6) & 1) ^ b1 ^ b2 ^ b3;
+    unsigned syn = s0 | (s1 << 1) | (s2 << 2);
+    static const int flip[8] = {-1, 4, 5, 0, 6, 1, 2, 3}; /* syndrome -> bit position */
+    if (syn) { c ^= 1u << flip[syn]; if (fixed) (*fixed)++; }
+    return c & 0xF;
+}
+size_t orc_hamming74_encoded_len(size_t nbytes) { return ((nbytes + 3) / 4) * 7; }
+size_t orc_hamming74_encode(const uint8_t *data, size_t nbytes, uint8_t *out) {
+    size_t nblk = (nbytes + 3) / 4;
+    for (size_t b = 0; b < nblk; b++) {
+        uint64_t acc = 0;
+        for (int i = 0; i < 8; i++) {
+            size_t by = b * 4 + (size_t)(i >> 1);
+            unsigned byte = by < nbytes ? data[by] : 0u;
+            unsigned nib = (i & 1) ? (byte >> 4) : (byte & 0xF);
+            acc |= (uint64_t)ham_enc_nibble(nib) << (7 * i);
+        }
+        for (int i = 0; i < 7; i++) out[b * 7 + (size_t)i] = (uint8_t)(acc >> (8 * i));
+    }
+    return nblk * 7;
+}
+size_t orc_hamming74_decode(const uint8_t *code, size_t nbytes, uint8_t *out, uint32_t *corrected) {
+    size_t nblk = nbytes / 7; /* a trailing partial block is dropped */
+    unsigned fixed = 0;
+    for (size_t b = 0; b < nblk; b++) {
+        uint64_t acc = 0;
+        for (int i = 0; i < 7; i++) acc |= (uint64_t)code[b * 7 + (size_t)i] << (8 * i);
+        for (int i = 0; i < 4; i++) {
+            unsigned lo = ham_dec_word((unsigned)((acc >> (14 * i)) & 0x7F), &fixed);
+            unsigned hi = ham_dec_word((unsigned)((acc >> (14 * i + 7)) & 0x7F), &fixed);
+            out[b * 4 + (size_t)i] = (uint8_t)(lo | (hi << 4));
+        }
+    }
+    if (corrected) *corrected = fixed;
+    return nblk * 4;
+}
+
+/* ------------------------------------------------------------------ RX chains */
+static orc_rx_info rx_chain(const oc64 *samples, size_t n, long offset, double f_delta, int n_fft, int cp,
+                            int guard, int modulation, const oc64 *training, int max_symbols, uint8_t *out,
+                            size_t out_cap, oc64 *soft, size_t soft_cap) {
+    orc_rx_info info;
+    memset(&info, 0, sizeof(info));
+    info.offset = offset;
+    info.f_delta = f_delta;
+    int S = n_fft + cp;
+    if (offset < 0 || (size_t)offset > n) { info.status = -3; return info; } /* split_off panics */
+    size_t len = n - (size_t)offset;
+    if (len < (size_t)(10 * S)) { info.status = -1; return info; } /* receiver.rs:27-29 */
+    /* split_into_chunks + pad_chunk (receiver.rs:192-210) */
+    size_t nchunks = (len + (size_t)S - 1) / (size_t)S;
+    size_t ndata_chunks = nchunks - 10;
+    if (max_symbols > 0 && ndata_chunks > (size_t)max_symbols) ndata_chunks = (size_t)max_symbols;
+    size_t used_chunks = 10 + ndata_chunks;
+    oc64 *buf = (oc64 *)calloc(used_chunks * (size_t)S, sizeof(oc64));
+    size_t ncopy = len < used_chunks * (size_t)S ? len : used_chunks * (size_t)S;
+    memcpy(buf, samples + offset, sizeof(oc64) * ncopy);
+    /* CFO derotation over every sample, sample_id from the trimmed start (receiver.rs:44-50) */
+    orc_cfo_rotate(buf, used_chunks * (size_t)S, f_delta, 0);
+    oc64 *hk = (oc64 *)malloc(sizeof(oc64) * (size_t)n_fft);
+    orc_estimate_channel(buf + 5 * (size_t)S, n_fft, cp, training, hk);
+    size_t nd = (size_t)orc_data_carriers(n_fft, guard);
+    oc64 *stream = (oc64 *)malloc(sizeof(oc64) * (ndata_chunks * nd + 1));
+    oc64 *blk = (oc64 *)malloc(sizeof(oc64) * (size_t)n_fft);
+    size_t ns = 0;
+    for (size_t c = 0; c < ndata_chunks; c++) {
+        orc_unprefix_block(buf + (10 + c) * (size_t)S, n_fft, cp, blk);
+        for (int i = 0; i < n_fft; i++) blk[i] = c_div(blk[i], hk[i]); /* receiver.rs:68-70 */
+        ns += orc_decode_block(blk, n_fft, guard, stream + ns);
+    }
+    if (soft) memcpy(soft, stream, sizeof(oc64) * (ns < soft_cap ? ns : soft_cap));
+    info.n_symbols = ndata_chunks;
+    uint8_t *dec = (uint8_t *)malloc(ns * (size_t)modulation / 8 + 16);
+    size_t nb = orc_demodulate(stream, ns, modulation, dec);
+    if (nb < 16) { info.status = -4; } /* drain(0..16) panics */
+    else {
+        /* header parse + truncate (receiver.rs:86-95); u128 LE, only the low 64 bits can be < usize::MAX */
+        uint64_t lo = 0, hi = 0;
+        for (int i = 0; i < 8; i++) { lo |= (uint64_t)dec[i] << (8 * i); hi |= (uint64_t)dec[8 + i] << (8 * i); }
+        size_t body = nb - 16;
+        size_t keep = (hi == 0 && lo < (uint64_t)body) ? (size_t)lo : body;
+        info.n_bytes = keep;
+        memcpy(out, dec + 16, keep < out_cap ? keep : out_cap);
+    }
+    free(dec); free(blk); free(stream); free(hk); free(buf);
+    return info;
+}
+
+orc_rx_info orc_decode_given(const oc64 *samples, size_t n, long offset, double f_delta, int n_fft, int cp,
+                             int guard, int modulation, const oc64 *training, int max_symbols, uint8_t *out,
+                             size_t out_cap, oc64 *soft, size_t soft_cap) {
+    return rx_chain(samples, n, offset, f_delta, n_fft, cp, guard, modulation, training, max_symbols, out, out_cap,
+                    soft, soft_cap);
+}
+
+/* receiver.rs:9-96 */
+orc_rx_info orc_decode_ref(const oc64 *samples, size_t n, int n_fft, int cp, int guard, int modulation,
+                           const oc64 *training, uint8_t *out, size_t out_cap, oc64 *soft, size_t soft_cap) {
+    int S = n_fft + cp;
+    oc64 *lock = (oc64 *)malloc(sizeof(oc64) * (size_t)S);
+    orc_locking_signal(S, lock);
+    oc64 *cross = (oc64 *)malloc(sizeof(oc64) * (2 * n - 1));
+    int idxmax = orc_xcorr_fft(samples, (int)n, lock, S, cross);
+    double peak = sqrt(c_norm_sqr(cross[idxmax]));
+    long offset = (long)idxmax - ((long)((2 * n - 1 - 1) / 2) + 1); /* receiver.rs:21 */
+    free(cross); free(lock);
+    orc_rx_info info;
+    memset(&info, 0, sizeof(info));
+    info.offset = offset;
+    info.metric = peak;
+    if (offset < 0 || (size_t)offset > n) { info.status = -3; return info; }
+    if (n - (size_t)offset < (size_t)(10 * S)) { info.status = -1; return info; }
+    /* frequency_correction(&chunks[3], &chunks[4]) (receiver.rs:39) */
+    double fd = orc_frequency_correction(samples + offset + 3 * S, samples + offset + 4 * S, S);
+    info = rx_chain(samples, n, offset, fd, n_fft, cp, guard, modulation, training, 0, out, out_cap, soft, soft_cap);
+    info.metric = peak;
+    return info;
+}
+
+orc_rx_info orc_decode_sc(const oc64 *samples, size_t n, int n_fft, int cp, int guard, int modulation,
+                          const oc64 *training, int window_reps, long sync_lags, double threshold, int backoff,
+                          int cfo_abs, int max_symbols, uint8_t *out, size_t out_cap, oc64 *soft, size_t soft_cap) {
+    int S = n_fft + cp;
+    orc_rx_info info;
+    memset(&info, 0, sizeof(info));
+    oc64 P; double metric, fd;
+    int d = orc_sc_sync(samples, n, S, window_reps, sync_lags, threshold, &P, &metric, &fd);
+    if (d < 0) { info.status = -2; return info; }
+    long offset = (long)d - (long)S - (long)backoff;
+    if (offset < 0) offset = 0;
+    if (cfo_abs) fd = fabs(fd);
+    info = rx_chain(samples, n, offset, fd, n_fft, cp, guard, modulation, training, max_symbols, out, out_cap, soft,
+                    soft_cap);
+    info.metric = metric;
+    return info;
+}
+
+size_t orc_rx_demod(const oc64 *samples, size_t n_symbols, int n_fft, int cp, int guard, int modulation,
+                    const oc64 *hk, uint8_t *out, oc64 *soft) {
+    int S = n_fft + cp;
+    size_t nd = (size_t)orc_data_carriers(n_fft, guard);
+    oc64 *stream = (oc64 *)malloc(sizeof(oc64) * (n_symbols * nd + 1));
+    oc64 *blk = (oc64 *)malloc(sizeof(oc64) * (size_t)n_fft);
+    size_t ns = 0;
+    for (size_t s = 0; s < n_symbols; s++) {
+        orc_unprefix_block(samples + s * (size_t)S, n_fft, cp, blk);
+        if (hk) for (int i = 0; i < n_fft; i++) blk[i] = c_div(blk[i], hk[i]);
+        ns += orc_decode_block(blk, n_fft, guard, stream + ns);
+    }
+    if (soft) memcpy(soft, stream, sizeof(oc64) * ns);
+    size_t nb = orc_demodulate(stream, ns, modulation, out);
+    free(blk); free(stream);
+    return nb;
+}
+
+/* ------------------------------------------------------------------ channel.rs */
+const double ORC_CHANNEL[64] = { /* channel.rs:26-31 */
+    0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -0.0000, -0.1912, 0.9316, 0.2821, -0.1990, 0.1630, -0.1017, 0.0544, -0.0261,
+    0.0090, 0.0000, -0.0034, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+    0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+    0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+
+/* channel.rs:33-74.  rand::thread_rng replaced by SplitMix64(seed): one U(0,1) draw for f_delta when
+ * timing_error, then (re, im) U(-1,1) draws per output sample. */
+size_t orc_channel(const oc64 *tx, size_t n, double snr_db, int timing_error, uint64_t seed, oc64 *out,
+                   double *f_delta_used) {
+    uint64_t st = seed;
+    double snr = pow(10.0, snr_db / 10.0);
+    oc64 h[64];
+    for (int i = 0; i < 64; i++) h[i] = c_new(ORC_CHANNEL[i], 0.0);
+    size_t m = n + 63;
+    orc_convolve(tx, (int)n, h, 64, out);
+    double fd = 0.0;
+    if (timing_error) {
+        fd = M_PI * (orc_uniform_01(&st) / 80.0); /* channel.rs:54 */
+        for (size_t i = 0; i < m; i++) {
+            oc64 comp = c_scale(c_scale(c_new(0.0, 1.0), fd), (double)(i + 1));
+            out[i] = c_mul(out[i], c_exp(comp));
+        }
+    }
+    if (f_delta_used) *f_delta_used = fd;
+    oc64 var = orc_variance(out, (int)m);
+    oc64 nv = c_new(var.re / snr, var.im / snr);
+    double complex sq = csqrt((0.5 * nv.re) + (0.5 * nv.im) * I); /* (0.5 * noise_var).sqrt() */
+    oc64 scale = c_new(creal(sq), cimag(sq));
+    for (size_t i = 0; i < m; i++) {
+        double re = orc_uniform_pm1(&st), im = orc_uniform_pm1(&st);
+        out[i] = c_add(out[i], c_mul(scale, c_new(re, im)));
+    }
+    return m;
+}
