@@ -1,0 +1,203 @@
+/*
+ * ofdm_hip.h -- C ABI of libofdm_hip.so: the MI355X (gfx950) OFDM modulate / demodulate hot path.
+ *
+ * This is the drop-in boundary for the DSP bodies of jkelleyrtp/ofdm's src/transmitter.rs and
+ * src/receiver.rs.  The reference has no FFI of its own (its hot path is plain `pub fn`s re-exported
+ * from src/lib.rs:8-21); each entry point below names the reference function (file:line) whose body it
+ * replaces.  The Rust host keeps its signatures and calls these through `extern "C"`
+ * (bindings/ofdm_hip.rs).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types; every call returns an `int` status
+ *     (0 = OFDM_OK, negative = error) and never throws or aborts across the boundary.
+ *   - sample buffers are interleaved IQ `fc32` = {float re, float im} (8 B), the reference's wire format
+ *     (src/utils.rs:228-254).  All `dev` pointers are DEVICE pointers on the context's GPU; buffers are
+ *     caller-owned.  Kernels are enqueued on the context's HIP stream and NOT synchronised: call
+ *     ofdm_synchronize() (or synchronise the stream you passed in) before reading results on the host.
+ *   - batch first: the reference's one-frame functions are the n_frames = 1 case.
+ *   - one context per (thread, GPU); a context is not thread-safe, different contexts are independent.
+ *   - CFO values are f64 rad/sample (frequency_correction returns f64, src/receiver.rs:231): an f32 CFO would
+ *     cost ~1e-5 rad of phase by the end of a 2000-sample frame.
+ *   - pilot tables (preamble, training) are INPUTS: the reference draws them from rand 0.8 StdRng
+ *     (src/transmitter.rs:75-96), which cannot be verified offline; ofdm_default_pilots() supplies the
+ *     documented SplitMix64 defaults.
+ *
+ * Extensions named by the north star that the reference lacks (64/256-QAM, Hamming(7,4), Schmidl-Cox,
+ * N != 64) are defined in DESIGN.md section 3 and restated on the CPU in oracle/ofdm_oracle.c.
+ */
+#ifndef OFDM_HIP_H
+#define OFDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFDM_HIP_ABI_VERSION 1
+
+typedef struct ofdm_ctx ofdm_ctx;
+typedef struct { float re, im; } ofdm_fc32;
+
+/* call status */
+enum {
+    OFDM_OK = 0,
+    OFDM_ERR_INVALID = -1,     /* bad argument / parameter combination */
+    OFDM_ERR_UNSUPPORTED = -2, /* valid request this build does not implement */
+    OFDM_ERR_NO_DEVICE = -3,   /* no HIP device / wrong architecture */
+    OFDM_ERR_HIP = -4,         /* a HIP runtime call failed (ofdm_last_hip_error) */
+    OFDM_ERR_NOMEM = -5
+};
+
+/* per-frame status written by ofdm_rx_decode_batch */
+enum {
+    OFDM_FRAME_OK = 0,
+    OFDM_FRAME_SHORT = -1,  /* "Input not long enough, bailing early" (src/receiver.rs:27-29) */
+    OFDM_FRAME_NOSYNC = -2, /* no lag reached the Schmidl-Cox threshold */
+    OFDM_FRAME_HEADER = -4  /* fewer than 16 decoded bytes (reference panics in drain, receiver.rs:88) */
+};
+
+/* ModulationScheme (src/transmitter.rs:98-104) as bits per constellation point */
+enum { OFDM_MOD_BPSK = 1, OFDM_MOD_QPSK = 2, OFDM_MOD_QAM16 = 4, OFDM_MOD_QAM64 = 6, OFDM_MOD_QAM256 = 8 };
+enum { OFDM_ECC_NONE = 0, OFDM_ECC_HAMMING74 = 1 };
+enum { OFDM_CFO_OFF = 0, OFDM_CFO_SIGNED = 1, OFDM_CFO_ABS = 2 }; /* ABS = reference's abs() (receiver.rs:239) */
+
+typedef struct {
+    int32_t n_fft;            /* sub-carriers: 64 (reference) .. 4096, power of two */
+    int32_t cp_len;           /* cyclic prefix, must be n_fft / 4 (reference: 16) */
+    int32_t modulation;       /* OFDM_MOD_* (reference default Bpsk, transmitter.rs:17) */
+    int32_t guard_bands;      /* 0 / 1 (reference default false, transmitter.rs:16) */
+    int32_t ecc;              /* OFDM_ECC_* applied to the payload around encode / decode */
+    int32_t sync_window_reps; /* Schmidl-Cox window W = reps * (n_fft + cp_len); 1..3, default 3 */
+    int32_t sync_backoff;     /* frame start = d_hat - L - backoff, default 4 */
+    int32_t cfo_mode;         /* OFDM_CFO_* , default SIGNED */
+    float sync_threshold;     /* packet-detect threshold on M(d), default 0.5 */
+    int32_t reserved[7];      /* must be zero */
+} ofdm_params;
+
+/* ------------------------------------------------------------------ library / context */
+int ofdm_abi_version(void);
+const char *ofdm_strerror(int status);
+int ofdm_device_count(int *count);
+/* reference defaults: 64 carriers, CP 16, BPSK, no guard bands, no ECC */
+int ofdm_default_params(ofdm_params *p);
+/* SplitMix64 pilot tables (interleaved re,im doubles): preamble[2*(n_fft+cp)] = 0.25*U(-1,1) seed 100
+ * (src/transmitter.rs:75-84), training[2*n_fft] = U(-1,1) seed 50 (src/transmitter.rs:88-96). Host call. */
+int ofdm_default_pilots(int32_t n_fft, int32_t cp_len, double *preamble, double *training);
+/* preamble / training: host pointers (interleaved doubles) or NULL for the defaults.
+ * device: HIP device ordinal.  stream: a hipStream_t (as void*) or NULL for a context-owned stream. */
+int ofdm_create(const ofdm_params *p, const double *preamble, const double *training, int device, void *stream,
+                ofdm_ctx **out);
+int ofdm_destroy(ofdm_ctx *ctx);
+int ofdm_set_stream(ofdm_ctx *ctx, void *stream);
+int ofdm_synchronize(ofdm_ctx *ctx);
+int ofdm_last_hip_error(const ofdm_ctx *ctx); /* raw hipError_t of the last failing HIP call */
+
+/* device-memory helpers so a host without its own HIP binding (the Rust crate) can stage buffers */
+int ofdm_dev_alloc(ofdm_ctx *ctx, size_t bytes, void **dev);
+int ofdm_dev_free(ofdm_ctx *ctx, void *dev);
+int ofdm_memcpy_h2d(ofdm_ctx *ctx, void *dev, const void *host, size_t bytes); /* async on the ctx stream */
+int ofdm_memcpy_d2h(ofdm_ctx *ctx, void *host, const void *dev, size_t bytes); /* synchronises the stream */
+int ofdm_memset(ofdm_ctx *ctx, void *dev, int value, size_t bytes);
+
+/* frame geometry for this context's parameters */
+int ofdm_symbol_len(const ofdm_ctx *ctx);            /* S = n_fft + cp_len */
+int ofdm_data_carriers(const ofdm_ctx *ctx);         /* 64k (no guard) or 48k */
+int ofdm_bytes_per_symbol(const ofdm_ctx *ctx);      /* data_carriers * modulation / 8 */
+int64_t ofdm_coded_len(const ofdm_ctx *ctx, int64_t payload_bytes);  /* after ECC (== payload when ECC off) */
+int64_t ofdm_data_symbols(const ofdm_ctx *ctx, int64_t payload_bytes); /* D = ceil((16+coded)*8/bps / carriers) */
+int64_t ofdm_frame_samples(const ofdm_ctx *ctx, int64_t payload_bytes); /* 10*S + D*S (transmitter.rs:22-54) */
+
+/* ------------------------------------------------------------------ stage-level entry points
+ * (mirror the reference's helper functions one to one; used by the parity tests and by hosts that
+ * want to keep part of the chain on the CPU) */
+
+/* SignalMut::fft / ifft (src/signals/mod.rs:27-58): n_vec transforms of length n_fft, unnormalised forward,
+ * inverse scaled by 1/n_fft.  in == out allowed. */
+int ofdm_fft_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, ofdm_fc32 *out_dev, int64_t n_vec, int inverse);
+/* prefix_block (src/transmitter.rs:168-181): n_sym blocks of n_fft bins -> n_sym blocks of n_fft+cp samples */
+int ofdm_ifft_cp_batch(ofdm_ctx *ctx, const ofdm_fc32 *freq_dev, ofdm_fc32 *out_dev, int64_t n_sym);
+/* unprefix_block (src/receiver.rs:99-104): n_sym blocks of n_fft+cp samples -> n_sym blocks of n_fft bins */
+int ofdm_unprefix_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, ofdm_fc32 *out_dev, int64_t n_sym);
+/* modulate (src/transmitter.rs:108-140) + 16/64/256-QAM: n_bytes -> ceil(8 n_bytes / bps) points */
+int ofdm_qam_map_batch(ofdm_ctx *ctx, const uint8_t *bytes_dev, int64_t n_bytes, ofdm_fc32 *out_dev);
+/* demodulate (src/receiver.rs:147-190): n_sym points (multiple of 8) -> n_sym*bps/8 bytes;
+ * idx_dev (optional) receives the per-point hard-decision index (bps-bit integer) */
+int ofdm_qam_demap_batch(ofdm_ctx *ctx, const ofdm_fc32 *sym_dev, int64_t n_sym, uint8_t *bytes_dev,
+                         uint8_t *idx_dev);
+/* encode_block (src/transmitter.rs:144-165): per symbol, data_carriers points -> n_fft bins with nulls/pilots */
+int ofdm_encode_block_batch(ofdm_ctx *ctx, const ofdm_fc32 *data_dev, ofdm_fc32 *bins_dev, int64_t n_sym);
+/* normalize (src/transmitter.rs:183-194): per frame, divide by max(0, max re, max im) */
+int ofdm_normalize_batch(ofdm_ctx *ctx, ofdm_fc32 *x_dev, int64_t n_frames, int64_t frame_stride, int64_t frame_len);
+/* Hamming(7,4): 4 data bytes <-> 7 code bytes (north-star extension).
+ * encode: n_bytes (zero-padded to a multiple of 4) -> ceil(n/4)*7; decode: floor(n/7)*4 bytes,
+ * corrected_dev (optional uint32) accumulates the number of corrected codewords. */
+int ofdm_hamming74_encode(ofdm_ctx *ctx, const uint8_t *in_dev, int64_t n_bytes, uint8_t *out_dev);
+int ofdm_hamming74_decode(ofdm_ctx *ctx, const uint8_t *in_dev, int64_t n_bytes, uint8_t *out_dev,
+                          uint32_t *corrected_dev);
+
+/* Schmidl-Cox sliding autocorrelation (north-star extension replacing xcorr_fft timing, receiver.rs:20-25).
+ * Frame f occupies in_dev[f*frame_stride .. +frame_len).  Lags d in [0, n_lags) (n_lags <= 0: every lag with
+ * d + W + L <= frame_len).  d_hat = first max of M over [d1, d1+W], d1 = first lag with M >= threshold;
+ * d_hat[f] = -1 if none.  f_delta[f] = arg P(d_hat)/L (signed, rad/sample), metric[f] = M(d_hat). */
+int ofdm_sc_correlate_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frames, int64_t frame_stride,
+                            int64_t frame_len, int64_t n_lags, int32_t *d_hat_dev, double *f_delta_dev,
+                            float *metric_dev);
+/* frequency_correction (src/receiver.rs:231-240): |mean_m angle(right[m]/left[m])| / L over n_pairs blocks of
+ * L = n_fft+cp samples; pair p reads left = in[p*stride ..], right = in[p*stride + right_offset ..] */
+int ofdm_frequency_correction_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_pairs, int64_t stride,
+                                    int64_t right_offset, double *f_delta_dev);
+/* CFO derotation (src/receiver.rs:44-50): x[f][n] *= exp(-j f_delta[f] (first_index[f] + n)), in place.
+ * first_index_dev may be NULL (0). */
+int ofdm_cfo_rotate_batch(ofdm_ctx *ctx, ofdm_fc32 *x_dev, int64_t n_frames, int64_t frame_stride,
+                          int64_t frame_len, const double *f_delta_dev, const int32_t *first_index_dev);
+/* estimate_channel (src/receiver.rs:212-229): H[k] = mean_b FFT(block_b minus CP)[k] / training[k] over the five
+ * training blocks starting at sample offset_dev[f] + 5*L of frame f (offset_dev NULL: 0).
+ * f_delta_dev (optional): blocks are derotated with sample_id counted from offset_dev[f]. hk_dev: n_frames*n_fft */
+int ofdm_estimate_channel_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frames, int64_t frame_stride,
+                                int64_t frame_len, const int32_t *offset_dev, const double *f_delta_dev,
+                                ofdm_fc32 *hk_dev);
+/* RX demod = unprefix_block + equalise + decode_block + demodulate (src/receiver.rs:64-83) over
+ * syms_per_frame OFDM symbols per frame.  Symbol k of frame f starts (at its cyclic prefix) at sample
+ * offset_dev[f] + first_symbol*L + k*L of the frame (offset_dev NULL: 0); samples at or beyond frame_len read
+ * as zero (pad_chunk, receiver.rs:203-210).  f_delta_dev (optional) derotates with sample_id counted from
+ * offset_dev[f].  hk_dev: per-frame channel (hk_stride = n_fft), shared (hk_stride = 0) or NULL (H == 1).
+ * out_dev[f*out_stride ..]: syms_per_frame * bytes_per_symbol bytes.  soft_dev (optional): equalised,
+ * phase-corrected data points, syms_per_frame*data_carriers per frame. */
+int ofdm_rx_demod_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frames, int64_t frame_stride,
+                        int64_t frame_len, int32_t first_symbol, int32_t syms_per_frame,
+                        const int32_t *offset_dev, const double *f_delta_dev, const ofdm_fc32 *hk_dev,
+                        int64_t hk_stride, uint8_t *out_dev, int64_t out_stride, ofdm_fc32 *soft_dev);
+
+/* ------------------------------------------------------------------ pipelines */
+
+/* encode (src/transmitter.rs:11-58) for a batch: frame f = [lock][preamble x4][training x5][data symbols],
+ * normalised per frame.  payload f = payload_dev[f*payload_stride .. + len_f), len_f = payload_len_dev[f] or
+ * payload_bytes when NULL; every frame is laid out for payload_bytes (D = ofdm_data_symbols(payload_bytes))
+ * and written to out_dev[f*out_stride ..] (out_stride >= ofdm_frame_samples(payload_bytes)).
+ * With ECC the payload is Hamming(7,4)-encoded first and the header carries the coded length. */
+int ofdm_tx_encode_batch(ofdm_ctx *ctx, const uint8_t *payload_dev, int64_t n_frames, int64_t payload_stride,
+                         const int32_t *payload_len_dev, int32_t payload_bytes, ofdm_fc32 *out_dev,
+                         int64_t out_stride);
+
+/* decode (src/receiver.rs:9-96) for a batch, with Schmidl-Cox timing/CFO in place of xcorr_fft:
+ * sync over n_lags lags -> offset = max(d_hat - L - backoff, 0) -> CFO derotation -> channel estimate ->
+ * per symbol FFT / equalise / pilot phase / demap -> 16-byte length header -> truncate [-> Hamming decode].
+ * At most max_symbols data symbols per frame are demodulated (fewer if the frame is shorter).
+ * out_dev[f*out_stride ..] receives out_len_dev[f] bytes (out_stride >= max_symbols*bytes_per_symbol).
+ * status/offset/f_delta/metric are per-frame outputs; any of offset/f_delta/metric may be NULL. */
+int ofdm_rx_decode_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frames, int64_t frame_stride,
+                         int64_t frame_len, int64_t n_lags, int32_t max_symbols, uint8_t *out_dev,
+                         int64_t out_stride, int32_t *out_len_dev, int32_t *status_dev, int32_t *offset_dev,
+                         double *f_delta_dev, float *metric_dev);
+
+/* ------------------------------------------------------------------ measurement helpers
+ * HIP events on the context's stream, so a host without HIP bindings can time kernels (bench.py). */
+int ofdm_timer_start(ofdm_ctx *ctx);
+int ofdm_timer_stop_ms(ofdm_ctx *ctx, float *elapsed_ms); /* records, synchronises, returns elapsed */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFDM_HIP_H */

@@ -1,0 +1,368 @@
+"""Host-side mirror of the reference's TX/RX function surface over the C ABI (include/ofdm_hip.h).
+
+The reference's hot path is a set of free functions re-exported from its crate root (src/lib.rs:8-21):
+`encode`, `decode`, `modulate`, `demodulate`, `encode_block`, `prefix_block`, `unprefix_block`,
+`estimate_channel`, `frequency_correction`, `normalize`, `locking_signal`, `preamble`, `training_signals`.
+This module keeps those names, argument meanings, defaults and error behaviour, batch-first, with the DSP
+bodies running as HIP kernels on one MI355X.  torch is used for device memory and streams only: every
+computation goes through libofdm_hip.so, and nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+BPSK, QPSK, QAM16, QAM64, QAM256 = 1, 2, 4, 6, 8  # ModulationScheme (src/transmitter.rs:98-104) as bits/point
+ECC_NONE, ECC_HAMMING74 = 0, 1
+CFO_OFF, CFO_SIGNED, CFO_ABS = 0, 1, 2
+FRAME_OK, FRAME_SHORT, FRAME_NOSYNC, FRAME_HEADER = 0, -1, -2, -4
+
+
+class OfdmError(RuntimeError):
+    pass
+
+
+class DecodeError(OfdmError):
+    """`Err(anyhow!(..))` of decode (src/receiver.rs:27-29)."""
+
+
+def _check(lib, rc: int, what: str, ctx=None):
+    if rc != 0:
+        extra = f" (hipError {lib.ofdm_last_hip_error(ctx)})" if ctx is not None and rc == -4 else ""
+        raise OfdmError(f"{what}: {lib.ofdm_strerror(rc).decode()}{extra}")
+
+
+def default_pilots(n_fft: int = 64):
+    """(preamble[n_fft+cp], training[n_fft]) complex128 -- SplitMix64 stand-ins for the StdRng tables of
+    src/transmitter.rs:75-96 (same seeds 100 / 50, same draw order and scaling)."""
+    lib = _lib.load()
+    cp = n_fft // 4
+    pre = np.zeros(n_fft + cp, np.complex128)
+    trn = np.zeros(n_fft, np.complex128)
+    _check(lib, lib.ofdm_default_pilots(n_fft, cp, pre.ctypes.data, trn.ctypes.data), "ofdm_default_pilots")
+    return pre, trn
+
+
+def locking_signal(length: int = 80) -> np.ndarray:
+    """src/transmitter.rs:60-72 (host-side constant; the library builds the same table into its frame header)."""
+    v = 0.5 * (np.arange(length) / (2.0 * length) + 0.5)
+    return np.fft.fftshift(v).astype(np.complex128) if length % 2 == 0 else np.roll(v, -((length + 1) // 2)) + 0j
+
+
+def preamble(length: int = 80) -> np.ndarray:
+    return default_pilots(length * 4 // 5)[0]
+
+
+def training_signals(length: int = 64) -> np.ndarray:
+    return default_pilots(length)[1]
+
+
+def _dev(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One (GPU, stream) context = `ofdm_ctx`.  Tensors passed in must live on this context's device."""
+
+    def __init__(self, n_fft: int = 64, modulation: int = BPSK, guard_bands: bool = False, ecc: int = ECC_NONE,
+                 device: int = 0, preamble: Optional[np.ndarray] = None, training: Optional[np.ndarray] = None,
+                 sync_window_reps: int = 3, sync_backoff: int = 4, cfo_mode: int = CFO_SIGNED,
+                 sync_threshold: float = 0.5, use_torch_stream: bool = True):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise OfdmError("no GPU visible: the OFDM hot path has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        p = _lib.Params()
+        _check(self.lib, self.lib.ofdm_default_params(C.byref(p)), "ofdm_default_params")
+        p.n_fft, p.cp_len, p.modulation, p.guard_bands, p.ecc = n_fft, n_fft // 4, modulation, int(guard_bands), ecc
+        p.sync_window_reps, p.sync_backoff, p.cfo_mode, p.sync_threshold = (sync_window_reps, sync_backoff, cfo_mode,
+                                                                            sync_threshold)
+        self.params = p
+        pre = None if preamble is None else np.ascontiguousarray(preamble, dtype=np.complex128)
+        trn = None if training is None else np.ascontiguousarray(training, dtype=np.complex128)
+        if pre is not None and pre.size != n_fft + n_fft // 4:
+            raise OfdmError("preamble must hold n_fft + cp samples")
+        if trn is not None and trn.size != n_fft:
+            raise OfdmError("training must hold n_fft bins")
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
+        h = C.c_void_p()
+        rc = self.lib.ofdm_create(C.byref(p), None if pre is None else pre.ctypes.data,
+                                  None if trn is None else trn.ctypes.data, device, C.c_void_p(stream), C.byref(h))
+        _check(self.lib, rc, "ofdm_create")
+        self.h = h
+        self.n_fft, self.cp, self.S = n_fft, n_fft // 4, n_fft + n_fft // 4
+        self.modulation, self.guard_bands, self.ecc = modulation, bool(guard_bands), ecc
+        self.data_carriers = self.lib.ofdm_data_carriers(h)
+        self.bytes_per_symbol = self.lib.ofdm_bytes_per_symbol(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ofdm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- helpers
+    def _ck(self, rc, what):
+        _check(self.lib, rc, what, self.h)
+
+    def synchronize(self):
+        self._ck(self.lib.ofdm_synchronize(self.h), "ofdm_synchronize")
+
+    def coded_len(self, payload_bytes: int) -> int:
+        return int(self.lib.ofdm_coded_len(self.h, payload_bytes))
+
+    def data_symbols(self, payload_bytes: int) -> int:
+        return int(self.lib.ofdm_data_symbols(self.h, payload_bytes))
+
+    def frame_samples(self, payload_bytes: int) -> int:
+        return int(self.lib.ofdm_frame_samples(self.h, payload_bytes))
+
+    def to_device(self, a, dtype=None) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            t = a.to(self.device)
+            return t if dtype is None else t.to(dtype)
+        arr = np.ascontiguousarray(a)
+        if np.iscomplexobj(arr):
+            arr = arr.astype(np.complex64)  # sig_to_bytes: f64 -> f32 pairs (src/utils.rs:228-236)
+        t = torch.from_numpy(arr).to(self.device)
+        return t if dtype is None else t.to(dtype)
+
+    def _cx(self, t: torch.Tensor) -> torch.Tensor:
+        if t.dtype != torch.complex64 or not t.is_contiguous() or t.device != self.device:
+            raise OfdmError("expected a contiguous complex64 tensor on the context's device")
+        return t
+
+    def _u8(self, t: torch.Tensor) -> torch.Tensor:
+        if t.dtype != torch.uint8 or not t.is_contiguous() or t.device != self.device:
+            raise OfdmError("expected a contiguous uint8 tensor on the context's device")
+        return t
+
+    def empty(self, shape, dtype) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # ---------------------------------------------------------------- stage level
+    def fft(self, x: torch.Tensor, inverse: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """SignalMut::fft / ifft (src/signals/mod.rs:27-58) over the last dim (== n_fft)."""
+        x = self._cx(x)
+        assert x.shape[-1] == self.n_fft
+        out = torch.empty_like(x) if out is None else self._cx(out)
+        self._ck(self.lib.ofdm_fft_batch(self.h, _dev(x), _dev(out), x.numel() // self.n_fft, int(inverse)), "fft")
+        return out
+
+    def prefix_block(self, freq: torch.Tensor) -> torch.Tensor:
+        """prefix_block::<N, N/4> (src/transmitter.rs:168-181): [..., N] bins -> [..., N+CP] samples."""
+        freq = self._cx(freq)
+        assert freq.shape[-1] == self.n_fft
+        out = self.empty(freq.shape[:-1] + (self.S,), torch.complex64)
+        self._ck(self.lib.ofdm_ifft_cp_batch(self.h, _dev(freq), _dev(out), freq.numel() // self.n_fft), "ifft_cp")
+        return out
+
+    def unprefix_block(self, blocks: torch.Tensor) -> torch.Tensor:
+        """unprefix_block (src/receiver.rs:99-104): [..., N+CP] samples -> [..., N] bins."""
+        blocks = self._cx(blocks)
+        assert blocks.shape[-1] == self.S
+        out = self.empty(blocks.shape[:-1] + (self.n_fft,), torch.complex64)
+        self._ck(self.lib.ofdm_unprefix_batch(self.h, _dev(blocks), _dev(out), blocks.numel() // self.S), "unprefix")
+        return out
+
+    def modulate(self, data: torch.Tensor) -> torch.Tensor:
+        """modulate (src/transmitter.rs:108-140): uint8[n] -> complex64[ceil(8n/bps)]."""
+        data = self._u8(data)
+        n = (data.numel() * 8 + self.modulation - 1) // self.modulation
+        out = self.empty((n,), torch.complex64)
+        self._ck(self.lib.ofdm_qam_map_batch(self.h, _dev(data), data.numel(), _dev(out)), "qam_map")
+        return out
+
+    def demodulate(self, sym: torch.Tensor, want_indices: bool = False):
+        """demodulate (src/receiver.rs:147-190): complex64[n], n % 8 == 0 -> uint8[n*bps/8]."""
+        sym = self._cx(sym)
+        n = sym.numel()
+        if n % 8 != 0:
+            raise OfdmError("demodulate: symbol count must be a multiple of 8 (receiver.rs:153)")
+        out = self.empty((n * self.modulation // 8,), torch.uint8)
+        idx = self.empty((n,), torch.uint8) if want_indices else None
+        self._ck(self.lib.ofdm_qam_demap_batch(self.h, _dev(sym), n, _dev(out), _dev(idx)), "qam_demap")
+        return (out, idx) if want_indices else out
+
+    def encode_block(self, data: torch.Tensor) -> torch.Tensor:
+        """encode_block (src/transmitter.rs:144-165): [n_sym, data_carriers] -> [n_sym, N]."""
+        data = self._cx(data)
+        assert data.shape[-1] == self.data_carriers
+        out = self.empty(data.shape[:-1] + (self.n_fft,), torch.complex64)
+        self._ck(self.lib.ofdm_encode_block_batch(self.h, _dev(data), _dev(out), data.numel() // self.data_carriers),
+                 "encode_block")
+        return out
+
+    def normalize(self, frames: torch.Tensor) -> torch.Tensor:
+        """normalize (src/transmitter.rs:183-194), in place, per row."""
+        frames = self._cx(frames)
+        f2 = frames.view(-1, frames.shape[-1])
+        self._ck(self.lib.ofdm_normalize_batch(self.h, _dev(f2), f2.shape[0], f2.shape[1], f2.shape[1]), "normalize")
+        return frames
+
+    def hamming74_encode(self, data: torch.Tensor) -> torch.Tensor:
+        data = self._u8(data)
+        out = self.empty(((data.numel() + 3) // 4 * 7,), torch.uint8)
+        self._ck(self.lib.ofdm_hamming74_encode(self.h, _dev(data), data.numel(), _dev(out)), "hamming74_encode")
+        return out
+
+    def hamming74_decode(self, code: torch.Tensor):
+        code = self._u8(code)
+        out = self.empty((code.numel() // 7 * 4,), torch.uint8)
+        fixed = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._ck(self.lib.ofdm_hamming74_decode(self.h, _dev(code), code.numel(), _dev(out), _dev(fixed)),
+                 "hamming74_decode")
+        return out, fixed
+
+    def sc_correlate(self, frames: torch.Tensor, frame_len: Optional[int] = None, n_lags: int = 0):
+        """Schmidl-Cox timing / CFO per row of `frames` [n_frames, stride] -> (d_hat i32, f_delta f64, metric f32)."""
+        frames = self._cx(frames)
+        f2 = frames.view(-1, frames.shape[-1])
+        n, stride = f2.shape
+        frame_len = stride if frame_len is None else frame_len
+        d = self.empty((n,), torch.int32)
+        fd = self.empty((n,), torch.float64)
+        m = self.empty((n,), torch.float32)
+        self._ck(self.lib.ofdm_sc_correlate_batch(self.h, _dev(f2), n, stride, frame_len, n_lags, _dev(d), _dev(fd),
+                                                  _dev(m)), "sc_correlate")
+        return d, fd, m
+
+    def frequency_correction(self, left_right: torch.Tensor) -> torch.Tensor:
+        """frequency_correction (src/receiver.rs:231-240): rows of [left(S) | right(S)] -> f64 |f_delta|."""
+        x = self._cx(left_right)
+        x2 = x.view(-1, 2 * self.S)
+        out = self.empty((x2.shape[0],), torch.float64)
+        self._ck(self.lib.ofdm_frequency_correction_batch(self.h, _dev(x2), x2.shape[0], 2 * self.S, self.S, _dev(out)),
+                 "frequency_correction")
+        return out
+
+    def cfo_rotate(self, frames: torch.Tensor, f_delta: torch.Tensor, first_index: Optional[torch.Tensor] = None):
+        """CFO derotation in place (src/receiver.rs:44-50)."""
+        frames = self._cx(frames)
+        f2 = frames.view(-1, frames.shape[-1])
+        assert f_delta.dtype == torch.float64 and f_delta.numel() == f2.shape[0]
+        self._ck(self.lib.ofdm_cfo_rotate_batch(self.h, _dev(f2), f2.shape[0], f2.shape[1], f2.shape[1], _dev(f_delta),
+                                                _dev(first_index)), "cfo_rotate")
+        return frames
+
+    def estimate_channel(self, frames: torch.Tensor, offset: Optional[torch.Tensor] = None,
+                         f_delta: Optional[torch.Tensor] = None, frame_len: Optional[int] = None) -> torch.Tensor:
+        """estimate_channel (src/receiver.rs:212-229) on the training blocks 5..9 of each frame row."""
+        frames = self._cx(frames)
+        f2 = frames.view(-1, frames.shape[-1])
+        hk = self.empty((f2.shape[0], self.n_fft), torch.complex64)
+        self._ck(self.lib.ofdm_estimate_channel_batch(self.h, _dev(f2), f2.shape[0], f2.shape[1],
+                                                      f2.shape[1] if frame_len is None else frame_len, _dev(offset),
+                                                      _dev(f_delta), _dev(hk)), "estimate_channel")
+        return hk
+
+    def rx_demod(self, frames: torch.Tensor, syms_per_frame: int, first_symbol: int = 0,
+                 offset: Optional[torch.Tensor] = None, f_delta: Optional[torch.Tensor] = None,
+                 hk: Optional[torch.Tensor] = None, frame_len: Optional[int] = None, want_soft: bool = False,
+                 out: Optional[torch.Tensor] = None):
+        """unprefix_block + equalise + decode_block + demodulate (src/receiver.rs:64-83) per OFDM symbol."""
+        frames = self._cx(frames)
+        f2 = frames.view(-1, frames.shape[-1])
+        n, stride = f2.shape
+        nb = syms_per_frame * self.bytes_per_symbol
+        out = self.empty((n, nb), torch.uint8) if out is None else self._u8(out)
+        soft = self.empty((n, syms_per_frame * self.data_carriers), torch.complex64) if want_soft else None
+        hk_stride = 0
+        if hk is not None:
+            hk = self._cx(hk)
+            hk_stride = self.n_fft if hk.dim() == 2 else 0  # [n_frames, N] per frame, [N] shared
+            assert hk.shape[-1] == self.n_fft and (hk.dim() == 1 or hk.shape[0] == n)
+        self._ck(self.lib.ofdm_rx_demod_batch(self.h, _dev(f2), n, stride, stride if frame_len is None else frame_len,
+                                              first_symbol, syms_per_frame, _dev(offset), _dev(f_delta), _dev(hk),
+                                              hk_stride, _dev(out), nb, _dev(soft)), "rx_demod")
+        return (out, soft) if want_soft else out
+
+    # ---------------------------------------------------------------- pipelines
+    def encode_batch(self, payload: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """encode (src/transmitter.rs:11-58) for every row of payload [n_frames, payload_bytes] (uint8)."""
+        payload = self._u8(payload)
+        n, nbytes = payload.shape
+        frame = self.frame_samples(nbytes)
+        out = self.empty((n, frame), torch.complex64) if out is None else self._cx(out)
+        self._ck(self.lib.ofdm_tx_encode_batch(self.h, _dev(payload), n, nbytes, None, nbytes, _dev(out), out.shape[-1]),
+                 "tx_encode")
+        return out
+
+    def decode_batch(self, frames: torch.Tensor, max_symbols: int, n_lags: int = 0, frame_len: Optional[int] = None):
+        """decode (src/receiver.rs:9-96) for every row of frames [n_frames, stride]; Schmidl-Cox timing/CFO."""
+        frames = self._cx(frames)
+        f2 = frames.view(-1, frames.shape[-1])
+        n, stride = f2.shape
+        ob = max(max_symbols * self.bytes_per_symbol - 16, 4)
+        out = self.empty((n, ob), torch.uint8)
+        res = {
+            "bytes": out, "len": self.empty((n,), torch.int32), "status": self.empty((n,), torch.int32),
+            "offset": self.empty((n,), torch.int32), "f_delta": self.empty((n,), torch.float64),
+            "metric": self.empty((n,), torch.float32),
+        }
+        self._ck(self.lib.ofdm_rx_decode_batch(self.h, _dev(f2), n, stride, stride if frame_len is None else frame_len,
+                                               n_lags, max_symbols, _dev(out), ob, _dev(res["len"]),
+                                               _dev(res["status"]), _dev(res["offset"]), _dev(res["f_delta"]),
+                                               _dev(res["metric"])), "rx_decode")
+        return res
+
+    # event timing on the context's stream (bench.py)
+    def timer_start(self):
+        self._ck(self.lib.ofdm_timer_start(self.h), "timer_start")
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        self._ck(self.lib.ofdm_timer_stop_ms(self.h, C.byref(ms)), "timer_stop")
+        return float(ms.value)
+
+
+# -------------------------------------------------------------------- reference-shaped free functions
+_CTX_CACHE = {}
+
+
+def _ctx(n_fft, modulation, guard_bands, ecc=ECC_NONE, **kw) -> Context:
+    key = (n_fft, modulation, bool(guard_bands), ecc, tuple(sorted(kw.items())))
+    if key not in _CTX_CACHE:
+        _CTX_CACHE[key] = Context(n_fft=n_fft, modulation=modulation, guard_bands=guard_bands, ecc=ecc, **kw)
+    return _CTX_CACHE[key]
+
+
+def encode(data: bytes, guard_bands: Optional[bool] = None, modulation: Optional[int] = None, n_fft: int = 64,
+           ecc: int = ECC_NONE) -> np.ndarray:
+    """`ofdm::encode!(data, guard_bands, modulation)` (src/transmitter.rs:10-58): bytes -> Vec<Complex64>.
+    Defaults as the reference: guard_bands=false, modulation=Bpsk."""
+    ctx = _ctx(n_fft, BPSK if modulation is None else modulation, bool(guard_bands), ecc)
+    pay = torch.frombuffer(bytearray(data) if len(data) else bytearray(1), dtype=torch.uint8)[: len(data)]
+    pay = pay.reshape(1, len(data)).to(ctx.device)
+    frames = ctx.encode_batch(pay)
+    ctx.synchronize()
+    return frames[0].cpu().numpy().astype(np.complex128)
+
+
+def decode(samples, guard_bands: Optional[bool] = None, modulation: Optional[int] = None, n_fft: int = 64,
+           ecc: int = ECC_NONE, **sync) -> bytes:
+    """`ofdm::decode!(samples, guard_bands, modulation)` (src/receiver.rs:8-96): Vec<Complex64> -> Result<Vec<u8>>.
+    Raises DecodeError("Input not long enough, bailing early") where the reference returns Err."""
+    ctx = _ctx(n_fft, BPSK if modulation is None else modulation, bool(guard_bands), ecc, **sync)
+    x = ctx.to_device(np.asarray(samples)).reshape(1, -1)
+    max_symbols = max((x.shape[1] + ctx.S - 1) // ctx.S - 10, 1)
+    res = ctx.decode_batch(x, max_symbols=max_symbols)
+    ctx.synchronize()
+    status = int(res["status"][0])
+    if status == FRAME_SHORT:
+        raise DecodeError("Input not long enough, bailing early")
+    if status != FRAME_OK:
+        raise DecodeError({FRAME_NOSYNC: "no preamble found", FRAME_HEADER: "no length header decoded"}.get(status, "decode failed"))
+    n = int(res["len"][0])
+    return bytes(res["bytes"][0, :n].cpu().numpy())

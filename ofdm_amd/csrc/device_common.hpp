@@ -1,0 +1,243 @@
+// device_common.hpp -- shared device-side building blocks for the gfx950 OFDM kernels.
+// Written for CDNA4 only: 64-lane wavefronts, LDS-staged Stockham passes, no MFMA (none of these stages is
+// a dense contraction; the kernels are HBM / VALU bound).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ofdm {
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cf_make(float x, float y) { return make_float2(x, y); }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf cmulc(cf a, cf b) { // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s, a.y * s); }
+// multiply by -j (forward) or +j (inverse)
+template <bool INV> __device__ __forceinline__ cf mul_mj(cf a) {
+    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+template <bool INV> __device__ __forceinline__ cf twid(cf w) { return INV ? make_float2(w.x, -w.y) : w; }
+
+// ---- carrier map (reference: src/transmitter.rs:150-161, src/receiver.rs:122-133), tiled k = N/64
+// class of reference bin c (0..63): 0 data, 1 null, 2 pilot
+__device__ __forceinline__ int carrier_class64(int c, int guard) {
+    if (!guard) return 0;
+    if (c >= 59 || c <= 5 || c == 32) return 1;
+    if (c == 6 || c == 25 || c == 39 || c == 58) return 2;
+    return 0;
+}
+// number of DATA classes below reference bin c (guard on): data classes are 7..58 minus {25,32,39,58}
+__device__ __forceinline__ int data_classes_below64(int c) {
+    if (c <= 7) return 0;
+    int n = c - 7;            // classes 7..c-1
+    n -= (c > 25) + (c > 32) + (c > 39) + (c > 58);
+    return n > 48 ? 48 : n;
+}
+
+// ---- radix-8 / radix-4 butterflies (decimation in frequency, natural-order outputs)
+template <bool INV> __device__ __forceinline__ void bfly8(cf *v) {
+    const float h = 0.70710678118654752440f;
+    cf a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+    cf a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    cf a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+    cf a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+    // a5 *= W8^1, a6 *= W8^2, a7 *= W8^3   (W8 = exp(-+ j pi/4))
+    a5 = INV ? make_float2((a5.x - a5.y) * h, (a5.x + a5.y) * h) : make_float2((a5.x + a5.y) * h, (a5.y - a5.x) * h);
+    a6 = mul_mj<INV>(a6);
+    a7 = INV ? make_float2((-a7.x - a7.y) * h, (a7.x - a7.y) * h) : make_float2((a7.y - a7.x) * h, (-a7.x - a7.y) * h);
+    cf b0 = cadd(a0, a2), b2 = csub(a0, a2);
+    cf b1 = cadd(a1, a3), b3 = mul_mj<INV>(csub(a1, a3));
+    cf b4 = cadd(a4, a6), b6 = csub(a4, a6);
+    cf b5 = cadd(a5, a7), b7 = mul_mj<INV>(csub(a5, a7));
+    v[0] = cadd(b0, b1); v[4] = csub(b0, b1);
+    v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
+    v[1] = cadd(b4, b5); v[5] = csub(b4, b5);
+    v[3] = cadd(b6, b7); v[7] = csub(b6, b7);
+}
+// radix-4 on v[o], v[o+2], v[o+4], v[o+6]
+template <bool INV> __device__ __forceinline__ void bfly4(cf *v, int o) {
+    cf s0 = cadd(v[o], v[o + 4]), d0 = csub(v[o], v[o + 4]);
+    cf s1 = cadd(v[o + 2], v[o + 6]), d1 = mul_mj<INV>(csub(v[o + 2], v[o + 6]));
+    v[o] = cadd(s0, s1); v[o + 4] = csub(s0, s1);
+    v[o + 2] = cadd(d0, d1); v[o + 6] = csub(d0, d1);
+}
+
+// ---- Stockham plan: log2(N) = 3a + 2b, radix-8 passes first then radix-4 (b in {0,1,2})
+template <int N> struct Plan {
+    static constexpr int LOG2 = (N == 64) ? 6 : (N == 128) ? 7 : (N == 256) ? 8 : (N == 512) ? 9
+                               : (N == 1024) ? 10 : (N == 2048) ? 11 : 12;
+    static constexpr int B4 = (LOG2 % 3 == 0) ? 0 : (LOG2 % 3 == 2) ? 1 : 2; // number of radix-4 passes
+    static constexpr int A8 = (LOG2 - 2 * B4) / 3;                           // number of radix-8 passes
+    static constexpr int PASSES = A8 + B4;
+    static constexpr int T = N / 8;                 // threads per OFDM symbol, 8 points each
+    static constexpr int WG = (T > 256) ? T : 256;  // workgroup size
+    static constexpr int G = WG / T;                // symbols per workgroup iteration
+    static constexpr int LDS_SYM = N + 8;           // per-symbol LDS stride (pad 8 points: conflict-free reads)
+    static constexpr bool WAVE_LOCAL = (T <= 64);   // a symbol's threads live in one wavefront: no barriers
+    // twiddle registers: 7 per radix-8 pass after the first, 6 per radix-4 pass
+    static constexpr int NTW = (A8 - 1) * 7 + B4 * 6;
+    __host__ __device__ static constexpr int radix(int p) { return p < A8 ? 8 : 4; }
+};
+
+// XOR swizzle inside aligned 8-point groups: turns the stride-8 writes of the first pass into conflict-free
+// ds_write_b64 groups while keeping unit-stride reads conflict-free.
+__device__ __forceinline__ int swz(int i) { return i ^ ((i >> 3) & 7); }
+
+template <int T> __device__ __forceinline__ void group_sync() {
+    if (T > 64) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// Load the per-thread twiddles for all passes after the first (loop invariant for a persistent thread).
+// tw[m] = exp(-2 pi i m / N), m < N (float2 table in global memory, produced on the host in f64).
+template <int N> __device__ __forceinline__ void load_twiddles(const cf *__restrict__ tw, int t, cf *w) {
+    typedef Plan<N> P;
+    int ns = 8, wi = 0;
+#pragma unroll
+    for (int p = 1; p < P::PASSES; ++p) {
+        if (P::radix(p) == 8) {
+            int k = t % ns, step = N / (ns * 8);
+#pragma unroll
+            for (int r = 1; r < 8; ++r) w[wi++] = tw[r * k * step];
+            ns *= 8;
+        } else {
+            int step = N / (ns * 4);
+            int ka = t % ns, kb = (t + P::T) % ns;
+#pragma unroll
+            for (int r = 1; r < 4; ++r) w[wi++] = tw[r * ka * step];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) w[wi++] = tw[r * kb * step];
+            ns *= 4;
+        }
+    }
+}
+
+// In-register/LDS FFT of one symbol spread over T threads: on entry v[m] = x[t + m*T], on exit v[m] = X[t + m*T].
+// buf: this symbol's LDS slab (LDS_SYM points).  Unnormalised in both directions.
+template <int N, bool INV> __device__ __forceinline__ void fft_symbol(cf *v, cf *buf, int t, const cf *w) {
+    typedef Plan<N> P;
+    int ns = 1, wi = 0;
+#pragma unroll
+    for (int p = 0; p < P::PASSES; ++p) {
+        if (p > 0) {
+            // read this pass's inputs (unit stride across the symbol's threads)
+            group_sync<P::T>();
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = buf[swz(t + m * P::T)];
+            group_sync<P::T>();
+        }
+        if (P::radix(p) == 8) {
+            if (p > 0) {
+#pragma unroll
+                for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twid<INV>(w[wi + r - 1]));
+                wi += 7;
+            }
+            bfly8<INV>(v);
+            if (p < P::PASSES - 1) {
+                int k = t % ns, base = (t / ns) * ns * 8 + k;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) buf[swz(base + r * ns)] = v[r];
+            }
+            ns *= 8;
+        } else {
+#pragma unroll
+            for (int r = 1; r < 4; ++r) v[2 * r] = cmul(v[2 * r], twid<INV>(w[wi + r - 1]));
+#pragma unroll
+            for (int r = 1; r < 4; ++r) v[2 * r + 1] = cmul(v[2 * r + 1], twid<INV>(w[wi + 3 + r - 1]));
+            wi += 6;
+            bfly4<INV>(v, 0);
+            bfly4<INV>(v, 1);
+            if (p < P::PASSES - 1) {
+                int ja = t, jb = t + P::T;
+                int basea = (ja / ns) * ns * 4 + ja % ns, baseb = (jb / ns) * ns * 4 + jb % ns;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    buf[swz(basea + r * ns)] = v[2 * r];
+                    buf[swz(baseb + r * ns)] = v[2 * r + 1];
+                }
+            }
+            ns *= 4;
+        }
+    }
+}
+
+// ---- CFO phasor exp(-j f_delta n) with the phase reduced in f64 (receiver.rs:44-50 runs in f64; an f32
+// product f_delta*n would lose ~1e-5 rad by n ~ 1e3).  turns = f_delta / (2 pi).
+__device__ __forceinline__ cf cfo_phasor(double turns, long long n) {
+    double ph = turns * (double)n;
+    ph -= rint(ph);                 // [-0.5, 0.5] turns, exact
+    float s, c;
+    sincospif(2.0f * (float)ph, &s, &c);
+    return make_float2(c, -s);
+}
+
+// ---- hard decisions (src/receiver.rs:147-190 for BPSK/QPSK; DESIGN.md 3.1 for 16/64/256-QAM)
+// returns the bps-bit index: bit j = j-th bit of the point in stream order
+__device__ __forceinline__ unsigned axis_bits(float x, int m) {
+    const int M = 1 << m;
+    float u = x * (float)(M - 1);
+    float f = floorf(u * 0.5f) + (float)(M / 2);
+    f = fminf(fmaxf(f, 0.0f), (float)(M - 1)); // NaN -> 0 (fmaxf returns the non-NaN operand)
+    unsigned l = (unsigned)f;
+    unsigned g = l ^ (l >> 1);                 // Gray code, MSB = first stream bit
+    return __brev(g) >> (32 - m);              // first stream bit at bit 0
+}
+__device__ __forceinline__ unsigned demap_point(cf z, int bps) {
+    if (bps == 1) return z.x > 0.0f ? 1u : 0u;                       // receiver.rs:162
+    if (bps == 2) {                                                   // receiver.rs:169-175, arms in order
+        float re = z.x, im = z.y;
+        if (re >= 0.0f && im >= 0.0f) return 3u;
+        if (re >= 0.0f && im <= 0.0f) return 1u;
+        if (re < 0.0f && im > 0.0f) return 2u;
+        return 0u;
+    }
+    const int m = bps >> 1;
+    return axis_bits(z.x, m) | (axis_bits(z.y, m) << m);
+}
+// map a bps-bit index to a constellation point (src/transmitter.rs:108-140; levels in [-1,1])
+__device__ __forceinline__ float axis_level(unsigned bits, int m) {
+    unsigned g = __brev(bits) >> (32 - m); // first stream bit -> Gray MSB
+    unsigned l = g;
+    l ^= l >> 1; l ^= l >> 2;              // Gray decode (m <= 4)
+    const int M = 1 << m;
+    return (float)(2 * (int)l - (M - 1)) / (float)(M - 1);
+}
+__device__ __forceinline__ cf map_point(unsigned idx, int bps) {
+    if (bps == 1) return make_float2((idx & 1u) ? 1.0f : -1.0f, 0.0f);
+    const int m = bps >> 1;
+    return make_float2(axis_level(idx & ((1u << m) - 1u), m), axis_level((idx >> m) & ((1u << m) - 1u), m));
+}
+// bps bits starting at bit `bit` of an LSB-first byte stream made of a 16-byte little-endian length header
+// followed by payload[0..len)  (src/packets/mod.rs:20-32, src/transmitter.rs:37-47); bits past the end are 0
+__device__ __forceinline__ unsigned stream_byte(const uint8_t *__restrict__ payload, long long len, long long by) {
+    if (by < 16) return by < 8 ? (unsigned)((unsigned long long)len >> (8 * by)) & 0xFFu : 0u;
+    by -= 16;
+    return by < len ? (unsigned)payload[by] : 0u;
+}
+__device__ __forceinline__ unsigned raw_bits(const uint8_t *__restrict__ bytes, long long n_bytes, long long bit, int bps) {
+    long long by = bit >> 3;
+    unsigned lo = by < n_bytes ? bytes[by] : 0u, hi = (by + 1) < n_bytes ? bytes[by + 1] : 0u;
+    return ((lo | (hi << 8)) >> (bit & 7)) & ((1u << bps) - 1u);
+}
+
+// ---- Hamming(7,4): codeword bits [d0 d1 d2 d3 p0 p1 p2], LSB first
+__device__ __forceinline__ unsigned ham_enc(unsigned d) {
+    unsigned d0 = d & 1u, d1 = (d >> 1) & 1u, d2 = (d >> 2) & 1u, d3 = (d >> 3) & 1u;
+    return (d & 0xFu) | ((d0 ^ d1 ^ d3) << 4) | ((d0 ^ d2 ^ d3) << 5) | ((d1 ^ d2 ^ d3) << 6);
+}
+__device__ __forceinline__ unsigned ham_dec(unsigned c, unsigned &fixed) {
+    unsigned b0 = c & 1u, b1 = (c >> 1) & 1u, b2 = (c >> 2) & 1u, b3 = (c >> 3) & 1u;
+    unsigned s0 = ((c >> 4) & 1u) ^ b0 ^ b1 ^ b3, s1 = ((c >> 5) & 1u) ^ b0 ^ b2 ^ b3, s2 = ((c >> 6) & 1u) ^ b1 ^ b2 ^ b3;
+    unsigned syn = s0 | (s1 << 1) | (s2 << 2);
+    // syndrome -> flipped bit position: 1:p0(4) 2:p1(5) 3:d0 4:p2(6) 5:d1 6:d2 7:d3, packed 3 bits each
+    const unsigned flip = (4u << 3) | (5u << 6) | (0u << 9) | (6u << 12) | (1u << 15) | (2u << 18) | (3u << 21);
+    if (syn) { c ^= 1u << ((flip >> (3 * syn)) & 7u); fixed++; }
+    return c & 0xFu;
+}
+
+} // namespace ofdm

@@ -1,0 +1,95 @@
+// kernels.hpp -- host-visible launch interface of the HIP kernels (internal to libofdm_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ofdm {
+
+struct SymParams {
+    // input samples / bins
+    const float2 *in = nullptr;
+    long long n_frames = 0;
+    long long frame_stride = 0; // samples between frame bases
+    long long frame_len = 0;    // valid samples per frame; reads at or beyond it return 0 (pad_chunk)
+    int syms_per_frame = 1;
+    int first_symbol = 0;       // symbol index (in units of in_sym_stride) of symbol 0
+    int in_sym_stride = 0;      // samples between consecutive symbols in the input
+    int in_skip = 0;            // samples skipped at the start of each symbol (cyclic prefix) on input
+    int sym_len = 0;            // S = N + CP
+    const int32_t *offset = nullptr;     // per-frame sample offset of the trimmed frame start
+    const double *f_delta = nullptr;     // per-frame CFO (rad/sample); sample ids count from offset[f]
+    const int32_t *nsym_frame = nullptr; // per-frame number of live symbols (demod)
+    // channel / tables
+    const float2 *hk = nullptr;
+    long long hk_stride = 0;
+    const float2 *tw = nullptr;           // exp(-2 pi i m / N)
+    const float2 *inv_training = nullptr; // 1 / training[k]
+    // outputs
+    float2 *out = nullptr;       // FFT / IFFT(+CP) / channel estimate / TX frames
+    long long out_stride_s = 0;  // TX: samples between output frames
+    unsigned char *out_bytes = nullptr;
+    long long out_stride = 0;    // bytes between per-frame outputs
+    float2 *soft = nullptr;
+    // modulation / TX
+    int bps = 1;
+    int guard = 0;
+    const uint8_t *payload = nullptr;
+    long long payload_stride = 0;
+    const int32_t *payload_len = nullptr;
+    int payload_bytes = 0;
+    unsigned *frame_max = nullptr; // per-frame max(0, re, im) as float bits
+};
+
+hipError_t run_fft(int n, const SymParams &p, bool inverse, hipStream_t st, int num_cu);
+hipError_t run_ifft_cp(int n, const SymParams &p, hipStream_t st, int num_cu);
+hipError_t run_demod(int n, const SymParams &p, hipStream_t st, int num_cu);
+hipError_t run_chest(int n, const SymParams &p, hipStream_t st, int num_cu);
+hipError_t run_tx_symbols(int n, const SymParams &p, hipStream_t st, int num_cu);
+
+// ---- Schmidl-Cox (kernels_sync.hip)
+struct ScParams {
+    const float2 *in = nullptr;
+    long long n_frames = 0, frame_stride = 0, frame_len = 0;
+    long long n_lags = 0;        // lags searched per frame (already clipped to the valid range)
+    int L = 0, W = 0;            // period and window
+    double threshold = 0.5;
+    int tiles_per_frame = 1;
+    int mode = 0;                // 0 fused (single tile), 1 first-crossing only, 2 peak search from lag_base
+    const int32_t *lag_base = nullptr; // mode 2: per-frame first lag (d1), -1 = skip
+    long long *cross = nullptr;        // mode 1: per-tile first crossing (or LLONG_MAX)
+    int32_t *d_hat = nullptr;
+    double *f_delta = nullptr;
+    float *metric = nullptr;
+};
+size_t sc_lds_bytes(const ScParams &p);
+hipError_t run_sc(const ScParams &p, hipStream_t st);
+hipError_t run_sc_min_cross(const long long *cross, int tiles_per_frame, long long n_frames, int32_t *d1, hipStream_t st);
+hipError_t run_freq_correction(const float2 *in, long long n_pairs, long long stride, long long right_offset, int L,
+                               double *f_delta, hipStream_t st);
+hipError_t run_cfo_rotate(float2 *x, long long n_frames, long long frame_stride, long long frame_len,
+                          const double *f_delta, const int32_t *first_index, hipStream_t st);
+
+// ---- byte / elementwise kernels (kernels_bytes.hip)
+hipError_t run_qam_map(const uint8_t *bytes, long long n_bytes, int bps, float2 *out, hipStream_t st);
+hipError_t run_qam_demap(const float2 *sym, long long n_sym, int bps, uint8_t *bytes, uint8_t *idx, hipStream_t st);
+hipError_t run_encode_block(const float2 *data, float2 *bins, long long n_sym, int n_fft, int guard, hipStream_t st);
+hipError_t run_frame_max(const float2 *x, long long n_frames, long long frame_stride, long long frame_len,
+                         unsigned *frame_max, hipStream_t st);
+hipError_t run_frame_scale(float2 *x, long long n_frames, long long frame_stride, long long frame_len,
+                           const unsigned *frame_max, hipStream_t st);
+hipError_t run_ham_encode(const uint8_t *in, long long n_frames, long long in_stride, const int32_t *in_len,
+                          long long n_bytes, uint8_t *out, long long out_stride, int32_t *out_len, hipStream_t st);
+hipError_t run_ham_decode(const uint8_t *in, long long n_bytes, uint8_t *out, uint32_t *corrected, hipStream_t st);
+// TX finish: write the 10 header blocks and divide the frame by its max (transmitter.rs:183-194)
+hipError_t run_tx_finish(float2 *out, long long n_frames, long long out_stride, int header_len, long long frame_len,
+                         const float2 *header, float header_max, const unsigned *frame_max, hipStream_t st);
+// RX prepare: d_hat -> status / offset / live symbols / CFO (receiver.rs:21-39)
+hipError_t run_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_delta, long long frame_len, int L,
+                          int backoff, int cfo_mode, int max_symbols, int bytes_per_symbol, int32_t *status,
+                          int32_t *offset, int32_t *nsym, hipStream_t st);
+// RX finish: header parse + truncate [+ Hamming decode] (receiver.rs:85-95)
+hipError_t run_rx_finish(const uint8_t *raw, long long raw_stride, long long n_frames, const int32_t *status,
+                         const int32_t *nsym, int bytes_per_symbol, int ecc, uint8_t *out, long long out_stride,
+                         int32_t *out_len, hipStream_t st);
+
+} // namespace ofdm

@@ -1,0 +1,267 @@
+// kernels_bytes.hip -- byte / element-wise stages: QAM map & demap, guard/pilot insert, per-frame normalise,
+// Hamming(7,4), TX header write, RX bookkeeping (timing -> offsets, length header, truncate).
+// All of these are HBM-bound integer/byte work with unit-stride access; none is shaped into a GEMM.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace ofdm {
+
+static inline unsigned grid_for(long long work, int block, long long cap = 2048LL * 8) {
+    long long g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    return (unsigned)(g < cap ? g : cap);
+}
+
+// modulate (src/transmitter.rs:108-140 + 16/64/256-QAM)
+__global__ __launch_bounds__(256) void k_qam_map(const uint8_t *bytes, long long n_bytes, int bps, cf *out,
+                                                 long long n_sym) {
+    for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < n_sym; s += (long long)gridDim.x * 256)
+        out[s] = map_point(raw_bits(bytes, n_bytes, s * bps, bps), bps);
+}
+hipError_t run_qam_map(const uint8_t *bytes, long long n_bytes, int bps, float2 *out, hipStream_t st) {
+    long long n_sym = (n_bytes * 8 + bps - 1) / bps;
+    if (n_sym <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_qam_map, dim3(grid_for(n_sym, 256)), dim3(256), 0, st, bytes, n_bytes, bps, out, n_sym);
+    return hipGetLastError();
+}
+
+// demodulate (src/receiver.rs:147-190): each thread produces bps bytes from 8 points
+__global__ __launch_bounds__(256) void k_qam_demap(const cf *sym, long long n_groups, int bps, uint8_t *bytes,
+                                                   uint8_t *idx) {
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n_groups; g += (long long)gridDim.x * 256) {
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned v = demap_point(sym[g * 8 + i], bps);
+            if (idx) idx[g * 8 + i] = (uint8_t)v;
+            acc |= (unsigned long long)v << (i * bps);
+        }
+        if (bytes)
+            for (int b = 0; b < bps; ++b) bytes[g * bps + b] = (uint8_t)(acc >> (8 * b));
+    }
+}
+hipError_t run_qam_demap(const float2 *sym, long long n_sym, int bps, uint8_t *bytes, uint8_t *idx, hipStream_t st) {
+    long long groups = n_sym / 8;
+    if (groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_qam_demap, dim3(grid_for(groups, 256)), dim3(256), 0, st, sym, groups, bps, bytes, idx);
+    return hipGetLastError();
+}
+
+// encode_block (src/transmitter.rs:144-165)
+__global__ __launch_bounds__(256) void k_encode_block(const cf *data, cf *bins, long long total, int n_fft, int guard) {
+    const int K = n_fft / 64, nd = guard ? 48 * K : n_fft;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long s = i / n_fft;
+        int bin = (int)(i - s * n_fft), c = bin / K, cls = carrier_class64(c, guard);
+        cf z = make_float2(0.f, 0.f);
+        if (cls == 2) z = make_float2(1.f, 0.f);
+        else if (cls == 0) z = data[s * nd + (guard ? data_classes_below64(c) * K + bin % K : bin)];
+        bins[i] = z;
+    }
+}
+hipError_t run_encode_block(const float2 *data, float2 *bins, long long n_sym, int n_fft, int guard, hipStream_t st) {
+    long long total = n_sym * n_fft;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_encode_block, dim3(grid_for(total, 256)), dim3(256), 0, st, data, bins, total, n_fft, guard);
+    return hipGetLastError();
+}
+
+// normalize (src/transmitter.rs:183-194), pass 1: per-frame max(0, re, im) as float bits (non-negative => ordered)
+__global__ __launch_bounds__(256) void k_frame_max(const cf *x, long long frame_stride, long long frame_len,
+                                                   unsigned *frame_max, int chunks) {
+    const long long f = blockIdx.x / chunks;
+    const int c = (int)(blockIdx.x - f * chunks);
+    const cf *row = x + f * frame_stride;
+    float mx = 0.f;
+    for (long long n = (long long)c * 2048 + threadIdx.x; n < frame_len && n < (long long)(c + 1) * 2048; n += 256) {
+        cf v = row[n];
+        mx = fmaxf(mx, fmaxf(v.x, v.y));
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(frame_max + f, __float_as_uint(mx));
+}
+__global__ __launch_bounds__(256) void k_frame_scale(cf *x, long long frame_stride, long long frame_len,
+                                                     const unsigned *frame_max, int chunks) {
+    const long long f = blockIdx.x / chunks;
+    const int c = (int)(blockIdx.x - f * chunks);
+    cf *row = x + f * frame_stride;
+    const float mx = __uint_as_float(frame_max[f]);
+    for (long long n = (long long)c * 2048 + threadIdx.x; n < frame_len && n < (long long)(c + 1) * 2048; n += 256) {
+        cf v = row[n];
+        row[n] = make_float2(v.x / mx, v.y / mx);
+    }
+}
+hipError_t run_frame_max(const float2 *x, long long n_frames, long long frame_stride, long long frame_len,
+                         unsigned *frame_max, hipStream_t st) {
+    if (n_frames <= 0 || frame_len <= 0) return hipSuccess;
+    long long chunks = (frame_len + 2047) / 2048;
+    if (chunks * n_frames > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_frame_max, dim3((unsigned)(chunks * n_frames)), dim3(256), 0, st, x, frame_stride, frame_len,
+                       frame_max, (int)chunks);
+    return hipGetLastError();
+}
+hipError_t run_frame_scale(float2 *x, long long n_frames, long long frame_stride, long long frame_len,
+                           const unsigned *frame_max, hipStream_t st) {
+    if (n_frames <= 0 || frame_len <= 0) return hipSuccess;
+    long long chunks = (frame_len + 2047) / 2048;
+    if (chunks * n_frames > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_frame_scale, dim3((unsigned)(chunks * n_frames)), dim3(256), 0, st, x, frame_stride,
+                       frame_len, frame_max, (int)chunks);
+    return hipGetLastError();
+}
+
+// Hamming(7,4) encode: one thread per 4-byte -> 7-byte block, per frame
+__global__ __launch_bounds__(256) void k_ham_encode(const uint8_t *in, long long n_frames, long long in_stride,
+                                                    const int32_t *in_len, long long n_bytes, uint8_t *out,
+                                                    long long out_stride, int32_t *out_len, long long blocks_per_frame) {
+    const long long total = n_frames * blocks_per_frame;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long f = i / blocks_per_frame, b = i - f * blocks_per_frame;
+        const long long len = in_len ? in_len[f] : n_bytes;
+        const uint8_t *src = in + f * in_stride;
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            long long by = b * 4 + (j >> 1);
+            unsigned byte = by < len ? src[by] : 0u;
+            unsigned nib = (j & 1) ? (byte >> 4) : (byte & 0xFu);
+            acc |= (unsigned long long)ham_enc(nib) << (7 * j);
+        }
+        uint8_t *dst = out + f * out_stride + b * 7;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) dst[j] = (uint8_t)(acc >> (8 * j));
+        if (out_len && b == 0) out_len[f] = (int32_t)(((len + 3) / 4) * 7);
+    }
+}
+hipError_t run_ham_encode(const uint8_t *in, long long n_frames, long long in_stride, const int32_t *in_len,
+                          long long n_bytes, uint8_t *out, long long out_stride, int32_t *out_len, hipStream_t st) {
+    long long bpf = (n_bytes + 3) / 4;
+    if (n_frames <= 0 || bpf <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ham_encode, dim3(grid_for(n_frames * bpf, 256)), dim3(256), 0, st, in, n_frames, in_stride,
+                       in_len, n_bytes, out, out_stride, out_len, bpf);
+    return hipGetLastError();
+}
+__device__ __forceinline__ void ham_decode_block(const uint8_t *src, uint8_t *dst, unsigned &fixed) {
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc |= (unsigned long long)src[j] << (8 * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned lo = ham_dec((unsigned)(acc >> (14 * j)) & 0x7Fu, fixed);
+        unsigned hi = ham_dec((unsigned)(acc >> (14 * j + 7)) & 0x7Fu, fixed);
+        dst[j] = (uint8_t)(lo | (hi << 4));
+    }
+}
+__global__ __launch_bounds__(256) void k_ham_decode(const uint8_t *in, long long n_blocks, uint8_t *out,
+                                                    uint32_t *corrected) {
+    unsigned fixed = 0;
+    for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < n_blocks; b += (long long)gridDim.x * 256)
+        ham_decode_block(in + b * 7, out + b * 4, fixed);
+    if (corrected) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) fixed += __shfl_xor(fixed, s, 64);
+        if ((threadIdx.x & 63) == 0 && fixed) atomicAdd(corrected, fixed);
+    }
+}
+hipError_t run_ham_decode(const uint8_t *in, long long n_bytes, uint8_t *out, uint32_t *corrected, hipStream_t st) {
+    long long blocks = n_bytes / 7;
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ham_decode, dim3(grid_for(blocks, 256)), dim3(256), 0, st, in, blocks, out, corrected);
+    return hipGetLastError();
+}
+
+// encode, last step (src/transmitter.rs:22-34, 56): copy the 10 constant header blocks in front of the data
+// symbols and divide the whole frame by max(0, re, im)
+__global__ __launch_bounds__(256) void k_tx_finish(cf *out, long long out_stride, int header_len, long long frame_len,
+                                                   const cf *header, float header_max, const unsigned *frame_max,
+                                                   int chunks) {
+    const long long f = blockIdx.x / chunks;
+    const int c = (int)(blockIdx.x - f * chunks);
+    cf *row = out + f * out_stride;
+    const float mx = fmaxf(header_max, __uint_as_float(frame_max[f]));
+    for (long long n = (long long)c * 2048 + threadIdx.x; n < frame_len && n < (long long)(c + 1) * 2048; n += 256) {
+        cf v = n < header_len ? header[n] : row[n];
+        row[n] = make_float2(v.x / mx, v.y / mx);
+    }
+}
+hipError_t run_tx_finish(float2 *out, long long n_frames, long long out_stride, int header_len, long long frame_len,
+                         const float2 *header, float header_max, const unsigned *frame_max, hipStream_t st) {
+    if (n_frames <= 0) return hipSuccess;
+    long long chunks = (frame_len + 2047) / 2048;
+    if (chunks * n_frames > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tx_finish, dim3((unsigned)(chunks * n_frames)), dim3(256), 0, st, out, out_stride,
+                       header_len, frame_len, header, header_max, frame_max, (int)chunks);
+    return hipGetLastError();
+}
+
+// decode bookkeeping (src/receiver.rs:21-39): timing -> trimmed offset, length check, live symbol count
+__global__ __launch_bounds__(256) void k_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_delta,
+                                                    long long frame_len, int L, int backoff, int cfo_mode,
+                                                    int max_symbols, int bytes_per_symbol, int32_t *status,
+                                                    int32_t *offset, int32_t *nsym) {
+    long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_frames) return;
+    int st = 0, off = 0, ns = 0;
+    const int d = d_hat[f];
+    if (d < 0) st = -2; // OFDM_FRAME_NOSYNC
+    else {
+        off = d - L - backoff;
+        if (off < 0) off = 0;
+        long long len = frame_len - off;
+        if (len < 10LL * L) st = -1; // "Input not long enough, bailing early"
+        else {
+            long long chunks = (len + L - 1) / L - 10; // split_into_chunks pads the tail chunk
+            ns = (int)(chunks < max_symbols ? chunks : max_symbols);
+            if ((long long)ns * bytes_per_symbol < 16) { st = -4; ns = 0; }
+        }
+    }
+    if (cfo_mode == 0) f_delta[f] = 0.0;
+    else if (cfo_mode == 2) f_delta[f] = fabs(f_delta[f]);
+    status[f] = st;
+    offset[f] = off;
+    nsym[f] = st == 0 ? ns : 0;
+}
+hipError_t run_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_delta, long long frame_len, int L,
+                          int backoff, int cfo_mode, int max_symbols, int bytes_per_symbol, int32_t *status,
+                          int32_t *offset, int32_t *nsym, hipStream_t st) {
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rx_prepare, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, n_frames, d_hat,
+                       f_delta, frame_len, L, backoff, cfo_mode, max_symbols, bytes_per_symbol, status, offset, nsym);
+    return hipGetLastError();
+}
+
+// header parse + truncate (src/receiver.rs:85-95) [+ Hamming(7,4) decode]: one wavefront per frame
+__global__ __launch_bounds__(256) void k_rx_finish(const uint8_t *raw, long long raw_stride, long long n_frames,
+                                                   const int32_t *status, const int32_t *nsym, int bytes_per_symbol,
+                                                   int ecc, uint8_t *out, long long out_stride, int32_t *out_len) {
+    const int lane = threadIdx.x & 63;
+    const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= n_frames) return;
+    if (status[f] != 0) { if (lane == 0) out_len[f] = 0; return; }
+    const uint8_t *src = raw + f * raw_stride;
+    const long long body = (long long)nsym[f] * bytes_per_symbol - 16;
+    unsigned long long lo = 0, hi = 0; // bincode fixint little-endian u128 (src/packets/mod.rs:20-32)
+    for (int i = 0; i < 8; ++i) { lo |= (unsigned long long)src[i] << (8 * i); hi |= (unsigned long long)src[8 + i] << (8 * i); }
+    const long long keep = (hi == 0 && lo < (unsigned long long)body) ? (long long)lo : body; // Vec::truncate
+    uint8_t *dst = out + f * out_stride;
+    if (!ecc) {
+        for (long long i = lane; i < keep; i += 64) dst[i] = src[16 + i];
+        if (lane == 0) out_len[f] = (int32_t)keep;
+    } else {
+        unsigned fixed = 0;
+        const long long blocks = keep / 7;
+        for (long long b = lane; b < blocks; b += 64) ham_decode_block(src + 16 + b * 7, dst + b * 4, fixed);
+        if (lane == 0) out_len[f] = (int32_t)(blocks * 4);
+    }
+}
+hipError_t run_rx_finish(const uint8_t *raw, long long raw_stride, long long n_frames, const int32_t *status,
+                         const int32_t *nsym, int bytes_per_symbol, int ecc, uint8_t *out, long long out_stride,
+                         int32_t *out_len, hipStream_t st) {
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rx_finish, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, st, raw, raw_stride, n_frames,
+                       status, nsym, bytes_per_symbol, ecc, out, out_stride, out_len);
+    return hipGetLastError();
+}
+
+} // namespace ofdm

@@ -1,0 +1,587 @@
+// ofdm_abi.hip -- the extern "C" boundary of libofdm_hip.so (include/ofdm_hip.h).
+// Context, parameter validation, host-side constant tables (f64 -> f32), workspace and the orchestration of
+// the TX / RX pipelines.  No exceptions cross the boundary; every HIP failure is mapped to OFDM_ERR_HIP.
+#include "../../include/ofdm_hip.h"
+#include "kernels.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace ofdm {
+int sc_tile_lags();
+}
+using namespace ofdm;
+
+namespace {
+
+struct Workspace {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+constexpr double kPi = 3.14159265358979323846;
+
+struct cd { double re, im; };
+static inline cd cd_mul(cd a, cd b) { return cd{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+
+// host f64 radix-2 FFT for the constant tables (product code: independent of oracle/)
+static void host_fft(std::vector<cd> &x, bool inverse) {
+    const size_t n = x.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(x[i], x[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t k = 0; k < len / 2; k++) {
+            double ang = (inverse ? 2.0 : -2.0) * kPi * (double)k / (double)len;
+            cd w{std::cos(ang), std::sin(ang)};
+            for (size_t i = k; i < n; i += len) {
+                cd u = x[i], v = cd_mul(x[i + len / 2], w);
+                x[i] = cd{u.re + v.re, u.im + v.im};
+                x[i + len / 2] = cd{u.re - v.re, u.im - v.im};
+            }
+        }
+    }
+    if (inverse)
+        for (auto &v : x) { v.re /= (double)n; v.im /= (double)n; }
+}
+
+static uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static double uniform_pm1(uint64_t &s) { return (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0; }
+
+static bool valid_nfft(int n) { return n >= 64 && n <= 4096 && (n & (n - 1)) == 0; }
+
+} // namespace
+
+struct ofdm_ctx {
+    ofdm_params prm;
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int last_hip = 0;
+    // constant device tables
+    float2 *d_tw = nullptr;       // exp(-2 pi i m / N)
+    float2 *d_inv_trn = nullptr;  // 1 / training[k]
+    float2 *d_header = nullptr;   // 10 * S un-normalised header samples
+    float header_max = 0.f;
+    // workspaces (grown on demand, never inside a captured region)
+    Workspace ws[8];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int S() const { return prm.n_fft + prm.cp_len; }
+    int carriers() const { return prm.guard_bands ? 48 * (prm.n_fft / 64) : prm.n_fft; }
+    int bytes_per_symbol() const { return carriers() * prm.modulation / 8; }
+};
+
+#define HIP_TRY(ctx, expr)                                   \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) { (ctx)->last_hip = (int)_e; return OFDM_ERR_HIP; } \
+    } while (0)
+
+static int ws_get(ofdm_ctx *c, int slot, size_t bytes, void **out) {
+    Workspace &w = c->ws[slot];
+    if (bytes > w.cap) {
+        if (w.ptr) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(w.ptr)); w.ptr = nullptr; w.cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&w.ptr, want);
+        if (e != hipSuccess) { c->last_hip = (int)e; w.ptr = nullptr; return OFDM_ERR_NOMEM; }
+        w.cap = want;
+    }
+    *out = w.ptr;
+    return OFDM_OK;
+}
+
+static SymParams base_params(const ofdm_ctx *c) {
+    SymParams p;
+    p.tw = c->d_tw;
+    p.inv_training = c->d_inv_trn;
+    p.sym_len = c->S();
+    p.bps = c->prm.modulation;
+    p.guard = c->prm.guard_bands;
+    return p;
+}
+
+extern "C" {
+
+int ofdm_abi_version(void) { return OFDM_HIP_ABI_VERSION; }
+
+const char *ofdm_strerror(int status) {
+    switch (status) {
+    case OFDM_OK: return "ok";
+    case OFDM_ERR_INVALID: return "invalid argument";
+    case OFDM_ERR_UNSUPPORTED: return "unsupported configuration";
+    case OFDM_ERR_NO_DEVICE: return "no usable HIP device";
+    case OFDM_ERR_HIP: return "HIP runtime error";
+    case OFDM_ERR_NOMEM: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+int ofdm_device_count(int *count) {
+    if (!count) return OFDM_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return OFDM_ERR_NO_DEVICE; }
+    *count = n;
+    return OFDM_OK;
+}
+
+int ofdm_default_params(ofdm_params *p) {
+    if (!p) return OFDM_ERR_INVALID;
+    std::memset(p, 0, sizeof(*p));
+    p->n_fft = 64;           // src/transmitter.rs:33,52
+    p->cp_len = 16;
+    p->modulation = OFDM_MOD_BPSK; // transmitter.rs:17
+    p->guard_bands = 0;            // transmitter.rs:16
+    p->ecc = OFDM_ECC_NONE;
+    p->sync_window_reps = 3;
+    p->sync_backoff = 4;
+    p->cfo_mode = OFDM_CFO_SIGNED;
+    p->sync_threshold = 0.5f;
+    return OFDM_OK;
+}
+
+int ofdm_default_pilots(int32_t n_fft, int32_t cp_len, double *preamble, double *training) {
+    if (!valid_nfft(n_fft) || cp_len != n_fft / 4) return OFDM_ERR_INVALID;
+    if (preamble) {
+        uint64_t s = 100; // transmitter.rs:76
+        for (int i = 0; i < n_fft + cp_len; i++) {
+            double re = uniform_pm1(s), im = uniform_pm1(s);
+            preamble[2 * i] = re * 0.25;
+            preamble[2 * i + 1] = im * 0.25;
+        }
+    }
+    if (training) {
+        uint64_t s = 50; // transmitter.rs:89
+        for (int i = 0; i < n_fft; i++) {
+            double re = uniform_pm1(s), im = uniform_pm1(s);
+            training[2 * i] = re * 1.0;
+            training[2 * i + 1] = im * 1.0;
+        }
+    }
+    return OFDM_OK;
+}
+
+int ofdm_destroy(ofdm_ctx *c) {
+    if (!c) return OFDM_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &w : c->ws) if (w.ptr) hipFree(w.ptr);
+    if (c->d_tw) hipFree(c->d_tw);
+    if (c->d_inv_trn) hipFree(c->d_inv_trn);
+    if (c->d_header) hipFree(c->d_header);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return OFDM_OK;
+}
+
+int ofdm_create(const ofdm_params *p, const double *preamble, const double *training, int device, void *stream,
+                ofdm_ctx **out) {
+    if (!p || !out) return OFDM_ERR_INVALID;
+    *out = nullptr;
+    if (!valid_nfft(p->n_fft) || p->cp_len != p->n_fft / 4) return OFDM_ERR_INVALID;
+    switch (p->modulation) {
+    case OFDM_MOD_BPSK: case OFDM_MOD_QPSK: case OFDM_MOD_QAM16: case OFDM_MOD_QAM64: case OFDM_MOD_QAM256: break;
+    default: return OFDM_ERR_INVALID;
+    }
+    if (p->guard_bands != 0 && p->guard_bands != 1) return OFDM_ERR_INVALID;
+    if (p->ecc != OFDM_ECC_NONE && p->ecc != OFDM_ECC_HAMMING74) return OFDM_ERR_INVALID;
+    if (p->sync_window_reps < 1 || p->sync_window_reps > 3) return OFDM_ERR_INVALID;
+    if (p->sync_backoff < 0 || p->sync_backoff > p->cp_len) return OFDM_ERR_INVALID;
+    if (p->cfo_mode < OFDM_CFO_OFF || p->cfo_mode > OFDM_CFO_ABS) return OFDM_ERR_INVALID;
+    if (!(p->sync_threshold > 0.f && p->sync_threshold <= 1.f)) return OFDM_ERR_INVALID;
+    for (int r : p->reserved) if (r != 0) return OFDM_ERR_INVALID;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return OFDM_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return OFDM_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return OFDM_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return OFDM_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return OFDM_ERR_NO_DEVICE; // gfx950 code objects only
+
+    ofdm_ctx *c = new (std::nothrow) ofdm_ctx();
+    if (!c) return OFDM_ERR_NOMEM;
+    c->prm = *p;
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int rc = OFDM_OK;
+    do {
+        if (stream) c->stream = (hipStream_t)stream;
+        else {
+            if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = OFDM_ERR_HIP; break; }
+            c->own_stream = true;
+        }
+        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = OFDM_ERR_HIP; break; }
+
+        const int N = p->n_fft, CP = p->cp_len, S = N + CP;
+        std::vector<double> pre(2 * S), trn(2 * N);
+        ofdm_default_pilots(N, CP, pre.data(), trn.data());
+        if (preamble) std::memcpy(pre.data(), preamble, sizeof(double) * 2 * S);
+        if (training) std::memcpy(trn.data(), training, sizeof(double) * 2 * N);
+
+        std::vector<float2> tw(N), inv(N), hdr(10 * S);
+        for (int m = 0; m < N; m++) {
+            double a = -2.0 * kPi * (double)m / (double)N;
+            tw[m] = make_float2((float)std::cos(a), (float)std::sin(a));
+            double re = trn[2 * m], im = trn[2 * m + 1], ns = re * re + im * im;
+            inv[m] = make_float2((float)(re / ns), (float)(-im / ns));
+        }
+        // header = [locking_signal(S)] [preamble x4] [prefix_block(training) x5]  (src/transmitter.rs:22-34)
+        std::vector<cd> lock(S);
+        for (int i = 0; i < S; i++) lock[i] = cd{0.5 * ((double)i / (2.0 * (double)S) + 0.5), 0.0}; // transmitter.rs:63-66
+        const int mid = (S + 1) / 2;                                                               // fft_shift, mod.rs:65
+        for (int i = 0; i < S; i++) { cd v = lock[(i + mid) % S]; hdr[i] = make_float2((float)v.re, (float)v.im); }
+        for (int r = 0; r < 4; r++)
+            for (int i = 0; i < S; i++) hdr[(1 + r) * S + i] = make_float2((float)pre[2 * i], (float)pre[2 * i + 1]);
+        std::vector<cd> t(N);
+        for (int i = 0; i < N; i++) t[i] = cd{trn[2 * i], trn[2 * i + 1]};
+        host_fft(t, true);
+        for (int r = 0; r < 5; r++) {
+            float2 *blk = hdr.data() + (5 + r) * S;
+            for (int i = 0; i < CP; i++) blk[i] = make_float2((float)t[N - CP + i].re, (float)t[N - CP + i].im);
+            for (int i = 0; i < N; i++) blk[CP + i] = make_float2((float)t[i].re, (float)t[i].im);
+        }
+        float hmax = 0.f;
+        for (auto &v : hdr) { hmax = std::fmax(hmax, v.x); hmax = std::fmax(hmax, v.y); }
+        c->header_max = hmax;
+
+        if (hipMalloc(&c->d_tw, sizeof(float2) * N) != hipSuccess || hipMalloc(&c->d_inv_trn, sizeof(float2) * N) != hipSuccess ||
+            hipMalloc(&c->d_header, sizeof(float2) * 10 * S) != hipSuccess) { rc = OFDM_ERR_NOMEM; break; }
+        if (hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_inv_trn, inv.data(), sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_header, hdr.data(), sizeof(float2) * 10 * S, hipMemcpyHostToDevice) != hipSuccess) { rc = OFDM_ERR_HIP; break; }
+    } while (0);
+    if (rc != OFDM_OK) { ofdm_destroy(c); return rc; }
+    *out = c;
+    return OFDM_OK;
+}
+
+int ofdm_set_stream(ofdm_ctx *c, void *stream) {
+    if (!c) return OFDM_ERR_INVALID;
+    if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->own_stream = false; }
+    c->stream = (hipStream_t)stream;
+    return OFDM_OK;
+}
+int ofdm_synchronize(ofdm_ctx *c) {
+    if (!c) return OFDM_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return OFDM_OK;
+}
+int ofdm_last_hip_error(const ofdm_ctx *c) { return c ? c->last_hip : 0; }
+
+int ofdm_dev_alloc(ofdm_ctx *c, size_t bytes, void **dev) {
+    if (!c || !dev) return OFDM_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(dev, bytes ? bytes : 1);
+    if (e != hipSuccess) { c->last_hip = (int)e; *dev = nullptr; return OFDM_ERR_NOMEM; }
+    return OFDM_OK;
+}
+int ofdm_dev_free(ofdm_ctx *c, void *dev) {
+    if (!c) return OFDM_ERR_INVALID;
+    if (dev) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(dev)); }
+    return OFDM_OK;
+}
+int ofdm_memcpy_h2d(ofdm_ctx *c, void *dev, const void *host, size_t bytes) {
+    if (!c || (bytes && (!dev || !host))) return OFDM_ERR_INVALID;
+    HIP_TRY(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return OFDM_OK;
+}
+int ofdm_memcpy_d2h(ofdm_ctx *c, void *host, const void *dev, size_t bytes) {
+    if (!c || (bytes && (!dev || !host))) return OFDM_ERR_INVALID;
+    HIP_TRY(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return OFDM_OK;
+}
+int ofdm_memset(ofdm_ctx *c, void *dev, int value, size_t bytes) {
+    if (!c || (bytes && !dev)) return OFDM_ERR_INVALID;
+    HIP_TRY(c, hipMemsetAsync(dev, value, bytes, c->stream));
+    return OFDM_OK;
+}
+
+int ofdm_symbol_len(const ofdm_ctx *c) { return c ? c->S() : OFDM_ERR_INVALID; }
+int ofdm_data_carriers(const ofdm_ctx *c) { return c ? c->carriers() : OFDM_ERR_INVALID; }
+int ofdm_bytes_per_symbol(const ofdm_ctx *c) { return c ? c->bytes_per_symbol() : OFDM_ERR_INVALID; }
+int64_t ofdm_coded_len(const ofdm_ctx *c, int64_t payload_bytes) {
+    if (!c || payload_bytes < 0) return OFDM_ERR_INVALID;
+    return c->prm.ecc == OFDM_ECC_HAMMING74 ? ((payload_bytes + 3) / 4) * 7 : payload_bytes;
+}
+int64_t ofdm_data_symbols(const ofdm_ctx *c, int64_t payload_bytes) {
+    if (!c || payload_bytes < 0) return OFDM_ERR_INVALID;
+    int64_t nsym = ((16 + ofdm_coded_len(c, payload_bytes)) * 8 + c->prm.modulation - 1) / c->prm.modulation;
+    return (nsym + c->carriers() - 1) / c->carriers();
+}
+int64_t ofdm_frame_samples(const ofdm_ctx *c, int64_t payload_bytes) {
+    if (!c || payload_bytes < 0) return OFDM_ERR_INVALID;
+    return (10 + ofdm_data_symbols(c, payload_bytes)) * (int64_t)c->S();
+}
+
+// ------------------------------------------------------------------ stage level
+int ofdm_fft_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_t n_vec, int inverse) {
+    if (!c || n_vec < 0 || (n_vec && (!in || !out))) return OFDM_ERR_INVALID;
+    SymParams p = base_params(c);
+    const int N = c->prm.n_fft;
+    p.in = reinterpret_cast<const float2 *>(in); p.out = reinterpret_cast<float2 *>(out);
+    p.n_frames = n_vec; p.frame_stride = N; p.frame_len = N; p.syms_per_frame = 1; p.in_sym_stride = N; p.in_skip = 0;
+    HIP_TRY(c, run_fft(N, p, inverse != 0, c->stream, c->num_cu));
+    return OFDM_OK;
+}
+int ofdm_ifft_cp_batch(ofdm_ctx *c, const ofdm_fc32 *freq, ofdm_fc32 *out, int64_t n_sym) {
+    if (!c || n_sym < 0 || (n_sym && (!freq || !out))) return OFDM_ERR_INVALID;
+    SymParams p = base_params(c);
+    const int N = c->prm.n_fft;
+    p.in = reinterpret_cast<const float2 *>(freq); p.out = reinterpret_cast<float2 *>(out);
+    p.n_frames = n_sym; p.frame_stride = N; p.frame_len = N; p.syms_per_frame = 1; p.in_sym_stride = N; p.in_skip = 0;
+    HIP_TRY(c, run_ifft_cp(N, p, c->stream, c->num_cu));
+    return OFDM_OK;
+}
+int ofdm_unprefix_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_t n_sym) {
+    if (!c || n_sym < 0 || (n_sym && (!in || !out))) return OFDM_ERR_INVALID;
+    SymParams p = base_params(c);
+    const int N = c->prm.n_fft, S = c->S();
+    p.in = reinterpret_cast<const float2 *>(in); p.out = reinterpret_cast<float2 *>(out);
+    p.n_frames = n_sym; p.frame_stride = S; p.frame_len = S; p.syms_per_frame = 1; p.in_sym_stride = S; p.in_skip = c->prm.cp_len;
+    HIP_TRY(c, run_fft(N, p, false, c->stream, c->num_cu));
+    return OFDM_OK;
+}
+int ofdm_qam_map_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, ofdm_fc32 *out) {
+    if (!c || n_bytes < 0 || (n_bytes && (!bytes || !out))) return OFDM_ERR_INVALID;
+    HIP_TRY(c, run_qam_map(bytes, n_bytes, c->prm.modulation, reinterpret_cast<float2 *>(out), c->stream));
+    return OFDM_OK;
+}
+int ofdm_qam_demap_batch(ofdm_ctx *c, const ofdm_fc32 *sym, int64_t n_sym, uint8_t *bytes, uint8_t *idx) {
+    if (!c || n_sym < 0 || (n_sym && !sym)) return OFDM_ERR_INVALID;
+    if (n_sym % 8 != 0) return OFDM_ERR_INVALID; // assert_eq!(remainder.len(), 0), src/receiver.rs:153
+    HIP_TRY(c, run_qam_demap(reinterpret_cast<const float2 *>(sym), n_sym, c->prm.modulation, bytes, idx, c->stream));
+    return OFDM_OK;
+}
+int ofdm_encode_block_batch(ofdm_ctx *c, const ofdm_fc32 *data, ofdm_fc32 *bins, int64_t n_sym) {
+    if (!c || n_sym < 0 || (n_sym && (!data || !bins))) return OFDM_ERR_INVALID;
+    HIP_TRY(c, run_encode_block(reinterpret_cast<const float2 *>(data), reinterpret_cast<float2 *>(bins), n_sym,
+                                c->prm.n_fft, c->prm.guard_bands, c->stream));
+    return OFDM_OK;
+}
+int ofdm_normalize_batch(ofdm_ctx *c, ofdm_fc32 *x, int64_t n_frames, int64_t frame_stride, int64_t frame_len) {
+    if (!c || n_frames < 0 || frame_len < 0 || frame_stride < frame_len || (n_frames && !x)) return OFDM_ERR_INVALID;
+    if (!n_frames) return OFDM_OK;
+    void *mx;
+    int rc = ws_get(c, 0, sizeof(unsigned) * (size_t)n_frames, &mx);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(mx, 0, sizeof(unsigned) * (size_t)n_frames, c->stream));
+    HIP_TRY(c, run_frame_max(reinterpret_cast<float2 *>(x), n_frames, frame_stride, frame_len, (unsigned *)mx, c->stream));
+    HIP_TRY(c, run_frame_scale(reinterpret_cast<float2 *>(x), n_frames, frame_stride, frame_len, (unsigned *)mx, c->stream));
+    return OFDM_OK;
+}
+int ofdm_hamming74_encode(ofdm_ctx *c, const uint8_t *in, int64_t n_bytes, uint8_t *out) {
+    if (!c || n_bytes < 0 || (n_bytes && (!in || !out))) return OFDM_ERR_INVALID;
+    HIP_TRY(c, run_ham_encode(in, 1, 0, nullptr, n_bytes, out, 0, nullptr, c->stream));
+    return OFDM_OK;
+}
+int ofdm_hamming74_decode(ofdm_ctx *c, const uint8_t *in, int64_t n_bytes, uint8_t *out, uint32_t *corrected) {
+    if (!c || n_bytes < 0 || (n_bytes >= 7 && (!in || !out))) return OFDM_ERR_INVALID;
+    HIP_TRY(c, run_ham_decode(in, n_bytes, out, corrected, c->stream));
+    return OFDM_OK;
+}
+
+static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                  int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric) {
+    const int L = c->S(), W = c->prm.sync_window_reps * L;
+    const int64_t valid = frame_len - W - L + 1;
+    if (valid <= 0) { // no lag fits: nothing can synchronise
+        HIP_TRY(c, hipMemsetAsync(d_hat, 0xFF, sizeof(int32_t) * (size_t)n_frames, c->stream));
+        if (f_delta) HIP_TRY(c, hipMemsetAsync(f_delta, 0, sizeof(double) * (size_t)n_frames, c->stream));
+        if (metric) HIP_TRY(c, hipMemsetAsync(metric, 0, sizeof(float) * (size_t)n_frames, c->stream));
+        return OFDM_OK;
+    }
+    if (n_lags <= 0 || n_lags > valid) n_lags = valid;
+    ScParams p;
+    p.in = in; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len; p.n_lags = n_lags;
+    p.L = L; p.W = W; p.threshold = (double)c->prm.sync_threshold;
+    p.d_hat = d_hat; p.f_delta = f_delta; p.metric = metric;
+    if (sc_lds_bytes(p) > 160 * 1024) return OFDM_ERR_UNSUPPORTED; // window does not fit one CU's LDS
+    const int CH = sc_tile_lags();
+    const int64_t tiles = (n_lags + CH - 1) / CH;
+    if (tiles == 1) {
+        p.tiles_per_frame = 1; p.mode = 0;
+        HIP_TRY(c, run_sc(p, c->stream));
+        return OFDM_OK;
+    }
+    if (tiles > 0x7fffffff) return OFDM_ERR_INVALID;
+    void *cross, *d1;
+    int rc = ws_get(c, 6, sizeof(long long) * (size_t)(n_frames * tiles), &cross);
+    if (rc) return rc;
+    rc = ws_get(c, 7, sizeof(int32_t) * (size_t)n_frames, &d1);
+    if (rc) return rc;
+    p.tiles_per_frame = (int)tiles; p.mode = 1; p.cross = (long long *)cross;
+    HIP_TRY(c, run_sc(p, c->stream));
+    HIP_TRY(c, run_sc_min_cross((const long long *)cross, (int)tiles, n_frames, (int32_t *)d1, c->stream));
+    p.tiles_per_frame = 1; p.mode = 2; p.lag_base = (const int32_t *)d1;
+    HIP_TRY(c, run_sc(p, c->stream));
+    return OFDM_OK;
+}
+
+int ofdm_sc_correlate_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int64_t frame_stride,
+                            int64_t frame_len, int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric) {
+    if (!c || n_frames < 0 || frame_len <= 0 || frame_stride < 0 || (n_frames && (!in || !d_hat))) return OFDM_ERR_INVALID;
+    if (n_frames > 1 && frame_stride <= 0) return OFDM_ERR_INVALID;
+    if (!n_frames) return OFDM_OK;
+    return sc_run(c, reinterpret_cast<const float2 *>(in), n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric);
+}
+int ofdm_frequency_correction_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_pairs, int64_t stride,
+                                    int64_t right_offset, double *f_delta) {
+    if (!c || n_pairs < 0 || (n_pairs && (!in || !f_delta))) return OFDM_ERR_INVALID;
+    HIP_TRY(c, run_freq_correction(reinterpret_cast<const float2 *>(in), n_pairs, stride, right_offset, c->S(), f_delta, c->stream));
+    return OFDM_OK;
+}
+int ofdm_cfo_rotate_batch(ofdm_ctx *c, ofdm_fc32 *x, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                          const double *f_delta, const int32_t *first_index) {
+    if (!c || n_frames < 0 || frame_len < 0 || (n_frames && (!x || !f_delta))) return OFDM_ERR_INVALID;
+    HIP_TRY(c, run_cfo_rotate(reinterpret_cast<float2 *>(x), n_frames, frame_stride, frame_len, f_delta, first_index, c->stream));
+    return OFDM_OK;
+}
+int ofdm_estimate_channel_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int64_t frame_stride,
+                                int64_t frame_len, const int32_t *offset, const double *f_delta, ofdm_fc32 *hk) {
+    if (!c || n_frames < 0 || frame_len <= 0 || (n_frames && (!in || !hk))) return OFDM_ERR_INVALID;
+    SymParams p = base_params(c);
+    p.in = reinterpret_cast<const float2 *>(in); p.out = reinterpret_cast<float2 *>(hk);
+    p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
+    p.offset = offset; p.f_delta = f_delta;
+    HIP_TRY(c, run_chest(c->prm.n_fft, p, c->stream, c->num_cu));
+    return OFDM_OK;
+}
+
+static int demod_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                     int first_symbol, int syms_per_frame, const int32_t *offset, const double *f_delta,
+                     const int32_t *nsym_frame, const float2 *hk, int64_t hk_stride, uint8_t *out, int64_t out_stride,
+                     float2 *soft) {
+    SymParams p = base_params(c);
+    p.in = in; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
+    p.first_symbol = first_symbol; p.syms_per_frame = syms_per_frame; p.in_sym_stride = c->S(); p.in_skip = c->prm.cp_len;
+    p.offset = offset; p.f_delta = f_delta; p.nsym_frame = nsym_frame;
+    p.hk = hk; p.hk_stride = hk_stride; p.out_bytes = out; p.out_stride = out_stride; p.soft = soft;
+    HIP_TRY(c, run_demod(c->prm.n_fft, p, c->stream, c->num_cu));
+    return OFDM_OK;
+}
+
+int ofdm_rx_demod_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                        int32_t first_symbol, int32_t syms_per_frame, const int32_t *offset, const double *f_delta,
+                        const ofdm_fc32 *hk, int64_t hk_stride, uint8_t *out, int64_t out_stride, ofdm_fc32 *soft) {
+    if (!c || n_frames < 0 || syms_per_frame < 0 || first_symbol < 0 || frame_len <= 0) return OFDM_ERR_INVALID;
+    if (n_frames && syms_per_frame && (!in || !out)) return OFDM_ERR_INVALID;
+    if (out_stride < (int64_t)syms_per_frame * c->bytes_per_symbol()) return OFDM_ERR_INVALID;
+    if (hk && hk_stride != 0 && hk_stride != c->prm.n_fft) return OFDM_ERR_INVALID;
+    if (!n_frames || !syms_per_frame) return OFDM_OK;
+    return demod_run(c, reinterpret_cast<const float2 *>(in), n_frames, frame_stride, frame_len, first_symbol,
+                     syms_per_frame, offset, f_delta, nullptr, reinterpret_cast<const float2 *>(hk), hk_stride, out,
+                     out_stride, reinterpret_cast<float2 *>(soft));
+}
+
+// ------------------------------------------------------------------ pipelines
+int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, int64_t payload_stride,
+                         const int32_t *payload_len, int32_t payload_bytes, ofdm_fc32 *out, int64_t out_stride) {
+    if (!c || n_frames < 0 || payload_bytes < 0 || payload_stride < 0) return OFDM_ERR_INVALID;
+    if (n_frames && (!out || (payload_bytes && !payload))) return OFDM_ERR_INVALID;
+    const int64_t frame = ofdm_frame_samples(c, payload_bytes);
+    if (out_stride < frame) return OFDM_ERR_INVALID;
+    if (!n_frames) return OFDM_OK;
+    const int S = c->S();
+    const uint8_t *src = payload; int64_t src_stride = payload_stride; const int32_t *src_len = payload_len;
+    int32_t src_bytes = payload_bytes;
+    if (c->prm.ecc == OFDM_ECC_HAMMING74) {
+        const int64_t coded = ofdm_coded_len(c, payload_bytes);
+        void *cw, *cl;
+        int rc = ws_get(c, 1, (size_t)(coded ? coded : 1) * (size_t)n_frames, &cw);
+        if (rc) return rc;
+        rc = ws_get(c, 2, sizeof(int32_t) * (size_t)n_frames, &cl);
+        if (rc) return rc;
+        HIP_TRY(c, run_ham_encode(payload, n_frames, payload_stride, payload_len, payload_bytes, (uint8_t *)cw, coded,
+                                  (int32_t *)cl, c->stream));
+        src = (const uint8_t *)cw; src_stride = coded; src_len = payload_len ? (const int32_t *)cl : nullptr;
+        src_bytes = (int32_t)coded;
+    }
+    void *mx;
+    int rc = ws_get(c, 0, sizeof(unsigned) * (size_t)n_frames, &mx);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(mx, 0, sizeof(unsigned) * (size_t)n_frames, c->stream));
+    SymParams p = base_params(c);
+    p.n_frames = n_frames; p.syms_per_frame = (int)ofdm_data_symbols(c, payload_bytes);
+    p.payload = src; p.payload_stride = src_stride; p.payload_len = src_len; p.payload_bytes = src_bytes;
+    p.out = reinterpret_cast<float2 *>(out); p.out_stride_s = out_stride; p.frame_max = (unsigned *)mx;
+    HIP_TRY(c, run_tx_symbols(c->prm.n_fft, p, c->stream, c->num_cu));
+    HIP_TRY(c, run_tx_finish(reinterpret_cast<float2 *>(out), n_frames, out_stride, 10 * S, frame, c->d_header,
+                             c->header_max, (const unsigned *)mx, c->stream));
+    return OFDM_OK;
+}
+
+int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                         int64_t n_lags, int32_t max_symbols, uint8_t *out, int64_t out_stride, int32_t *out_len,
+                         int32_t *status, int32_t *offset, double *f_delta, float *metric) {
+    if (!c || n_frames < 0 || frame_len <= 0 || max_symbols <= 0) return OFDM_ERR_INVALID;
+    if (n_frames && (!in || !out || !out_len || !status)) return OFDM_ERR_INVALID;
+    if (n_frames > 1 && frame_stride <= 0) return OFDM_ERR_INVALID;
+    const int bps_bytes = c->bytes_per_symbol();
+    const int64_t raw_stride = (int64_t)max_symbols * bps_bytes;
+    if (out_stride < raw_stride - 16 && c->prm.ecc == OFDM_ECC_NONE) return OFDM_ERR_INVALID;
+    if (!n_frames) return OFDM_OK;
+    const int N = c->prm.n_fft;
+    void *w_dhat, *w_fd, *w_off, *w_nsym, *w_hk, *w_raw;
+    int rc;
+    if ((rc = ws_get(c, 0, sizeof(int32_t) * (size_t)n_frames, &w_dhat))) return rc;
+    if ((rc = ws_get(c, 1, sizeof(double) * (size_t)n_frames, &w_fd))) return rc;
+    if ((rc = ws_get(c, 2, sizeof(int32_t) * (size_t)n_frames, &w_off))) return rc;
+    if ((rc = ws_get(c, 3, sizeof(int32_t) * (size_t)n_frames, &w_nsym))) return rc;
+    if ((rc = ws_get(c, 4, sizeof(float2) * (size_t)N * (size_t)n_frames, &w_hk))) return rc;
+    if ((rc = ws_get(c, 5, (size_t)raw_stride * (size_t)n_frames, &w_raw))) return rc;
+    int32_t *offs = offset ? offset : (int32_t *)w_off;
+    double *fd = f_delta ? f_delta : (double *)w_fd;
+    const float2 *x = reinterpret_cast<const float2 *>(in);
+    // 1. timing + CFO: Schmidl-Cox over the repeated preamble (replaces xcorr_fft, src/receiver.rs:20-25,39)
+    rc = sc_run(c, x, n_frames, frame_stride, frame_len, n_lags, (int32_t *)w_dhat, fd, metric);
+    if (rc) return rc;
+    // 2. trimmed start, length check, live symbols (receiver.rs:21-36)
+    HIP_TRY(c, run_rx_prepare(n_frames, (const int32_t *)w_dhat, fd, frame_len, c->S(), c->prm.sync_backoff,
+                              c->prm.cfo_mode, max_symbols, bps_bytes, status, offs, (int32_t *)w_nsym, c->stream));
+    // 3. channel estimate from the 5 training blocks, CFO-derotated (receiver.rs:44-56)
+    {
+        SymParams p = base_params(c);
+        p.in = x; p.out = (float2 *)w_hk; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
+        p.offset = offs; p.f_delta = fd;
+        HIP_TRY(c, run_chest(N, p, c->stream, c->num_cu));
+    }
+    // 4. per data symbol: CP strip + FFT + equalise + pilot phase + demap (receiver.rs:64-83)
+    rc = demod_run(c, x, n_frames, frame_stride, frame_len, 10, max_symbols, offs, fd, (const int32_t *)w_nsym,
+                   (const float2 *)w_hk, N, (uint8_t *)w_raw, raw_stride, nullptr);
+    if (rc) return rc;
+    // 5. length header, truncate [, Hamming decode] (receiver.rs:85-95)
+    HIP_TRY(c, run_rx_finish((const uint8_t *)w_raw, raw_stride, n_frames, status, (const int32_t *)w_nsym, bps_bytes,
+                             c->prm.ecc, out, out_stride, out_len, c->stream));
+    return OFDM_OK;
+}
+
+int ofdm_timer_start(ofdm_ctx *c) {
+    if (!c) return OFDM_ERR_INVALID;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    return OFDM_OK;
+}
+int ofdm_timer_stop_ms(ofdm_ctx *c, float *ms) {
+    if (!c || !ms) return OFDM_ERR_INVALID;
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return OFDM_OK;
+}
+
+} // extern "C"
