@@ -86,7 +86,8 @@ int ofdm_default_params(ofdm_params *p);
  * (src/transmitter.rs:75-84), training[2*n_fft] = U(-1,1) seed 50 (src/transmitter.rs:88-96). Host call. */
 int ofdm_default_pilots(int32_t n_fft, int32_t cp_len, double *preamble, double *training);
 /* preamble / training: host pointers (interleaved doubles) or NULL for the defaults.
- * device: HIP device ordinal.  stream: a hipStream_t (as void*) or NULL for a context-owned stream. */
+ * device: HIP device ordinal.  stream: a hipStream_t (as void*); NULL = the device's default (null) stream,
+ * which is what torch uses as its current stream unless told otherwise. */
 int ofdm_create(const ofdm_params *p, const double *preamble, const double *training, int device, void *stream,
                 ofdm_ctx **out);
 int ofdm_destroy(ofdm_ctx *ctx);

@@ -220,11 +220,8 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc = OFDM_OK;
     do {
-        if (stream) c->stream = (hipStream_t)stream;
-        else {
-            if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = OFDM_ERR_HIP; break; }
-            c->own_stream = true;
-        }
+        c->stream = (hipStream_t)stream; // NULL = the device's default (null) stream
+
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = OFDM_ERR_HIP; break; }
 
         const int N = p->n_fft, CP = p->cp_len, S = N + CP;

@@ -296,7 +296,7 @@ def run_decode_parity(api, orc, n, mod, guard, ecc, nbytes, nfr, span_extra, see
         tx = orc.encode(body, guard, mod, n)
         d = int(rng.integers(1, span_extra - 30))
         fd = (rng.random() * (0.95 if cfo_abs else 1.9) - (0.0 if cfo_abs else 0.95)) * np.pi / S
-        caps.append(through_channel(orc, rng, tx, span, d, fd, snr_db)); pays.append(pay)
+        caps.append(through_channel(orc, rng, tx, span, d, fd, snr_db, data_start=10 * S)); pays.append(pay)
     caps = np.stack(caps)
     res = ctx.decode_batch(dev(ctx, caps), max_symbols=D)
     ctx.synchronize()
@@ -356,7 +356,7 @@ def test_decode_errors(api, orc):
     rng = np.random.default_rng(4)
     tx = orc.encode(b"hello world", False, orc.BPSK)
     with pytest.raises(api.DecodeError, match="Input not long enough"):
-        api.decode(through_channel(orc, rng, tx[:700], 900, 3, 0.0, 30.0))
+        api.decode(through_channel(orc, rng, tx[:700], 800, 3, 0.0, 30.0))
     with pytest.raises(api.DecodeError):
         api.decode(np.zeros(3000, np.complex64))
 

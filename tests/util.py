@@ -46,15 +46,17 @@ def make_symbols(orc, rng, n_sym, n_fft, guard, mod, snr_db=30.0):
     return fc32(x), data
 
 
-def through_channel(orc, rng, tx, span, delay, f_delta, snr_db=30.0, taps=True):
+def through_channel(orc, rng, tx, span, delay, f_delta, snr_db=30.0, taps=True, data_start=None):
     """Config-3 style capture: `delay` leading zeros, FIR CHANNEL (src/channel.rs:26-31), CFO
-    exp(+j f (i+1)) (channel.rs:58-62), AWGN, cut/padded to `span` samples."""
+    exp(+j f (i+1)) (channel.rs:58-62), AWGN, cut/padded to `span` samples.
+    The SNR is set against the power of the DATA symbols (tx[data_start:]): the lock / preamble blocks are
+    time-domain constants while IFFT output shrinks as 1/N, so for large N the header would dominate."""
     y = np.convolve(tx, orc.channel_taps())[: tx.size + 24] if taps else tx.copy()
     buf = np.zeros(span, np.complex128)
     n = min(span - delay, y.size)
     buf[delay:delay + n] = y[:n]
     buf *= np.exp(1j * f_delta * np.arange(1, span + 1))
-    p = np.mean(np.abs(y) ** 2)
+    p = np.mean(np.abs(y[data_start or 0:]) ** 2)
     if snr_db is not None:
         buf += awgn(rng, span, np.sqrt(p / 10 ** (snr_db / 10) / 2))
     return fc32(buf)
