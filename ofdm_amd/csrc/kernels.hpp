@@ -40,6 +40,22 @@ struct SymParams {
     unsigned *frame_max = nullptr; // per-frame max(0, re, im) as float bits
 };
 
+// N = 64 RX-demod fast path (kernels_fast.hip)
+struct Fast64Params {
+    const float2 *in = nullptr;
+    long long frame_stride = 0;
+    int first_symbol = 0;
+    const float2 *hk = nullptr; // shared channel or nullptr
+    const float2 *tw = nullptr;
+    unsigned char *out = nullptr;
+    long long out_stride = 0;
+    int groups_per_frame = 1;   // 8-symbol groups per frame
+    long long n_groups = 0, stride_groups = 0;
+    long long f0 = 0, blk_df = 0, wave_df = 0, step_df = 0; // frame index bookkeeping without division
+    int k0 = 0, blk_dk = 0, wave_dk = 0, step_dk = 0;
+};
+hipError_t run_demod64_fast(const SymParams &p, hipStream_t st, int num_cu);
+
 hipError_t run_fft(int n, const SymParams &p, bool inverse, hipStream_t st, int num_cu);
 hipError_t run_ifft_cp(int n, const SymParams &p, hipStream_t st, int num_cu);
 hipError_t run_demod(int n, const SymParams &p, hipStream_t st, int num_cu);

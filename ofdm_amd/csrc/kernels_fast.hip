@@ -1,0 +1,181 @@
+// kernels_fast.hip -- the N = 64 RX-demod fast path (BASELINE config 2): CP strip + FFT64 + [equalise] + pilot
+// phase + hard demap + LSB-first bit packing, for regularly spaced, HBM-resident symbols.
+//
+// Wave-centric: one 64-lane wavefront owns 8 consecutive OFDM symbols (8 lanes x 8 points each) per iteration and
+// never meets a workgroup barrier.  Per iteration and lane:
+//   8 x global_load_dwordx2 with immediate offsets (the 128-byte cyclic prefix of each 640-byte symbol is a whole,
+//     aligned cache line and is never fetched), scalar base address, no integer division anywhere;
+//   radix-8 butterfly -> XOR-swizzled LDS slab -> radix-8 butterfly (7 loop-invariant twiddles in registers);
+//   pilot phase: atan2 on the 4 pilot lanes, 3 DPP adds inside the 8-lane group, one sincos;
+//   hard decisions; bit fields OR-ed into the wave's packed output image in LDS (ds_or_b32), then the image is
+//   stored with unit-stride dword stores (36 B per symbol for 64-QAM with guard bands).
+// Roofline: HBM -- 640 algorithmic bytes read per symbol (512 actually fetched) + packed bytes written.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+extern "C" __device__ float __ocml_atan2pi_f32(float, float); // atan2(y, x) / pi (ROCm device library)
+
+namespace ofdm {
+
+// DPP helpers: sum over the 8 lanes of a symbol group (lanes 8s .. 8s+7)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum8(float x) {
+    x += dpp_f<0xB1>(x);  // quad_perm [1,0,3,2]  : lane ^ 1
+    x += dpp_f<0x4E>(x);  // quad_perm [2,3,0,1]  : lane ^ 2
+    x += dpp_f<0x141>(x); // row_half_mirror      : lane -> 7 - lane inside each 8-lane half row
+    return x;
+}
+
+template <int BPS, bool GUARD, bool HK>
+__global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
+    constexpr int N = 64, S = 80, CP = 16;
+    constexpr int ND = GUARD ? 48 : 64;          // data carriers per symbol
+    constexpr int REGION_DW = ND * BPS / 4;      // packed output of 8 symbols, in dwords
+    constexpr int SLAB = 8 * 72;                 // 8 symbols x (64 + 8 pad) points
+
+    __shared__ cf slab_all[4 * SLAB];
+    __shared__ unsigned img_all[4 * REGION_DW];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = lane >> 3, t = lane & 7;
+    cf *buf = slab_all + wave * SLAB + s * 72;
+    unsigned *img = img_all + wave * REGION_DW;
+
+    // loop-invariant per-lane constants
+    cf w[7];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) w[r - 1] = p.tw[r * t];
+    cf g[8];
+    if (HK) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { // 1 / H  (equalise: Y /= H, src/receiver.rs:68-70)
+            cf h = p.hk[t + 8 * m];
+            float ns = h.x * h.x + h.y * h.y;
+            g[m] = make_float2(h.x / ns, -h.y / ns);
+        }
+    }
+    int bitoff[8]; // bit offset of bin (t + 8m)'s field inside the wave's packed image, -1 = not a data bin
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int c = t + 8 * m;
+        const int q = GUARD ? data_classes_below64(c) : c;
+        bitoff[m] = (carrier_class64(c, GUARD) == 0) ? (s * ND + q) * BPS : -1;
+    }
+    const int wr = swz(8 * t);      // first-pass write base (r is XOR-ed in below)
+    const int lane_off = s * S + t; // sample offset of this lane inside the 8-symbol group
+
+    // wave-uniform iteration state (no division in the loop: the host supplies the per-step increments)
+    long long f = p.f0 + (long long)blockIdx.x * p.blk_df + wave * p.wave_df;
+    int kk = p.k0 + (int)((blockIdx.x * (long long)p.blk_dk + wave * p.wave_dk));
+    // normalise kk into [0, groups_per_frame)
+    f += kk / p.groups_per_frame;
+    kk %= p.groups_per_frame;
+    long long g_idx = (long long)blockIdx.x * 4 + wave;
+
+    for (; g_idx < p.n_groups; g_idx += p.stride_groups) {
+        const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + kk * 8) * S + CP + lane_off;
+        cf v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = src[8 * m];
+
+        bfly8<false>(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];   // swz(8t + r) = 8t + (r ^ t) = swz(8t) ^ r
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)]; // swz(t + 8m): (i >> 3) & 7 = m
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+        bfly8<false>(v);
+        // v[m] = X[t + 8m]
+
+        if (HK) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], g[m]);
+        }
+        if (GUARD) {
+            // decode_block (src/receiver.rs:106-145): mean of the 4 pilot angles, rotate data points by -phase
+            // pilots sit at bins 6, 25, 39, 58 = lanes t = 6 (m 0), 1 (m 3), 7 (m 4), 2 (m 7); the other lanes
+            // feed (1, 0) -> angle 0, so ONE atan2 evaluation serves the whole wave
+            cf pv = make_float2(1.f, 0.f);
+            pv = (t == 6) ? v[0] : pv;
+            pv = (t == 1) ? v[3] : pv;
+            pv = (t == 7) ? v[4] : pv;
+            pv = (t == 2) ? v[7] : pv;
+            // angles kept in units of pi: atan2pi / sincospi need no large-argument reduction
+            const float ang = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.25f;
+            float sn, cs;
+            sincospif(ang, &sn, &cs);
+            const cf rot = make_float2(cs, -sn);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
+        }
+        // clear the packed image, OR every field in, store it
+        for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (bitoff[m] >= 0) {
+                const unsigned idx = demap_point(v[m], BPS);
+                const int wd = bitoff[m] >> 5, sh = bitoff[m] & 31;
+                atomicOr(&img[wd], idx << sh);
+                if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)
+                    if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
+                }
+            }
+        }
+        unsigned *dst = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)kk * 8 * (ND * BPS / 8));
+        for (int i = lane; i < REGION_DW; i += 64) dst[i] = img[i];
+
+        // advance (wave-uniform)
+        f += p.step_df;
+        kk += p.step_dk;
+        if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; }
+    }
+}
+
+template <int BPS> static hipError_t launch_bps(const Fast64Params &p, bool guard, dim3 grid, hipStream_t st) {
+    const bool hk = p.hk != nullptr;
+    if (guard && hk) hipLaunchKernelGGL((k_demod64<BPS, true, true>), grid, dim3(256), 0, st, p);
+    else if (guard) hipLaunchKernelGGL((k_demod64<BPS, true, false>), grid, dim3(256), 0, st, p);
+    else if (hk) hipLaunchKernelGGL((k_demod64<BPS, false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_demod64<BPS, false, false>), grid, dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// Returns hipErrorNotSupported when the request is outside the fast path's envelope (caller falls back to k_sym).
+hipError_t run_demod64_fast(const SymParams &sp, hipStream_t st, int num_cu) {
+    if (sp.offset || sp.f_delta || sp.nsym_frame || sp.soft) return hipErrorNotSupported;
+    if (sp.syms_per_frame <= 0 || (sp.syms_per_frame & 7) != 0) return hipErrorNotSupported;
+    if (sp.hk && sp.hk_stride != 0) return hipErrorNotSupported;
+    if ((long long)(sp.first_symbol + sp.syms_per_frame) * 80 > sp.frame_len) return hipErrorNotSupported; // no tail padding
+    if ((reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
+    if (reinterpret_cast<uintptr_t>(sp.in) & 7) return hipErrorNotSupported;
+    Fast64Params p;
+    p.in = sp.in; p.frame_stride = sp.frame_stride; p.first_symbol = sp.first_symbol;
+    p.hk = sp.hk; p.tw = sp.tw; p.out = sp.out_bytes; p.out_stride = sp.out_stride;
+    p.groups_per_frame = sp.syms_per_frame / 8;
+    p.n_groups = sp.n_frames * (long long)p.groups_per_frame;
+    if (p.n_groups <= 0) return hipSuccess;
+    long long waves = (p.n_groups + 3) / 4 * 4;
+    long long cap = (long long)num_cu * 8 * 4; // 8 workgroups per CU
+    if (waves > cap) waves = cap;
+    const int grid = (int)(waves / 4);
+    p.stride_groups = (long long)grid * 4;
+    const int gpf = p.groups_per_frame;
+    p.f0 = 0; p.k0 = 0;
+    p.blk_df = 4 / gpf; p.blk_dk = 4 % gpf;    // a block advances the group index by 4
+    p.wave_df = 0; p.wave_dk = 1;              // a wave by 1 (normalised in the kernel)
+    p.step_df = p.stride_groups / gpf; p.step_dk = (int)(p.stride_groups % gpf);
+    switch (sp.bps) {
+    case 1: return launch_bps<1>(p, sp.guard != 0, dim3(grid), st);
+    case 2: return launch_bps<2>(p, sp.guard != 0, dim3(grid), st);
+    case 4: return launch_bps<4>(p, sp.guard != 0, dim3(grid), st);
+    case 6: return launch_bps<6>(p, sp.guard != 0, dim3(grid), st);
+    case 8: return launch_bps<8>(p, sp.guard != 0, dim3(grid), st);
+    default: return hipErrorNotSupported;
+    }
+}
+
+} // namespace ofdm

@@ -469,6 +469,11 @@ static int demod_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t fr
     p.first_symbol = first_symbol; p.syms_per_frame = syms_per_frame; p.in_sym_stride = c->S(); p.in_skip = c->prm.cp_len;
     p.offset = offset; p.f_delta = f_delta; p.nsym_frame = nsym_frame;
     p.hk = hk; p.hk_stride = hk_stride; p.out_bytes = out; p.out_stride = out_stride; p.soft = soft;
+    if (c->prm.n_fft == 64) { // regular, aligned streams take the wave-centric fast path (kernels_fast.hip)
+        hipError_t e = run_demod64_fast(p, c->stream, c->num_cu);
+        if (e == hipSuccess) return OFDM_OK;
+        if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
+    }
     HIP_TRY(c, run_demod(c->prm.n_fft, p, c->stream, c->num_cu));
     return OFDM_OK;
 }
