@@ -13,6 +13,7 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace ofdm {
 
@@ -44,19 +45,22 @@ __global__ __launch_bounds__(SC_WG) void k_sc_tile(ScParams p) {
     Sums *wsum = reinterpret_cast<Sums *>(smem + (size_t)span * sizeof(cf)); // [4] wave totals
     Cand *wcand = reinterpret_cast<Cand *>(wsum + 4);                          // [4]
     int *wmin = reinterpret_cast<int *>(wcand + 4);                            // [4]
-    __shared__ int s_d1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long f = blockIdx.x / p.tiles_per_frame;
-    const int tile = (int)(blockIdx.x - f * p.tiles_per_frame);
     const int L = p.L, W = p.W;
+    // slow-list mode: persistent workgroups redo the listed frames (one tile each); otherwise one (frame, tile) per block
+    const long long n_items = p.slow_list ? (long long)*p.slow_count : 1;
+  for (long long item = p.slow_list ? (long long)blockIdx.x : 0; item < n_items; item += p.slow_list ? (long long)gridDim.x : 1) {
+    if (p.slow_list) __syncthreads();
+    const long long f = p.slow_list ? (long long)p.slow_list[item] : (long long)(blockIdx.x / p.tiles_per_frame);
+    const int tile = p.slow_list ? 0 : (int)(blockIdx.x - f * p.tiles_per_frame);
 
     long long d0;
     if (p.mode == 2) {
         int lb = p.lag_base[f];
         if (lb < 0) { // no crossing anywhere in this frame
             if (tid == 0) { p.d_hat[f] = -1; if (p.f_delta) p.f_delta[f] = 0.0; if (p.metric) p.metric[f] = 0.f; }
-            return;
+            continue;
         }
         d0 = lb;
     } else d0 = (long long)tile * SC_CH;
@@ -155,11 +159,11 @@ __global__ __launch_bounds__(SC_WG) void k_sc_tile(ScParams p) {
         d1 = m01 < m23 ? m01 : m23;
         if (p.mode == 1) {
             if (tid == 0) p.cross[blockIdx.x] = d1 == INT_MAX ? LLONG_MAX : d0 + d1;
-            return;
+            continue;
         }
         if (d1 == INT_MAX) {
             if (tid == 0) { p.d_hat[f] = -1; if (p.f_delta) p.f_delta[f] = 0.0; if (p.metric) p.metric[f] = 0.f; }
-            return;
+            continue;
         }
     }
     // ---- (B) first maximum of M over [d1, d1 + W]
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(SC_WG) void k_sc_tile(ScParams p) {
             if (p.metric) p.metric[f] = (float)(b.num / b.den);
         }
     }
+  } // item loop
 }
 
 size_t sc_lds_bytes(const ScParams &p) {
@@ -207,6 +212,357 @@ hipError_t run_sc(const ScParams &p, hipStream_t st) {
     return hipGetLastError();
 }
 int sc_tile_lags() { return SC_CH; }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_sc_fast: the fast Schmidl-Cox path for one-tile frames with a short period (W + L well below the 2560-sample
+// tile, i.e. N <= 256) and 16-byte aligned frame bases.  "Filter in f32, decide in f64":
+//   * persistent 512-thread workgroups (2 per CU) walk the frame list; a frame's raw fc32 samples arrive by
+//     direct-to-LDS loads (global_load_lds_dwordx4 from inline asm: no VGPR staging, not drained by barriers) into a
+//     double buffer, so frame k+1 is in flight while frame k is correlated (staging alone streams at 6.4 TB/s);
+//   * every product q[n] = conj(r[n]) r[n+L] and energy e[n] = |r[n]|^2 is formed ONCE, in f32; each thread owns 5
+//     consecutive samples and writes its exclusive local prefix sums to LDS; the scan over the thread totals is a
+//     DPP wavefront scan (row shifts / broadcasts) plus 8 wave totals;
+//   * a lag is four prefix differences:  P(d) = C_q[d+W] - C_q[d],  E(d) = C_e[d+W] - C_e[d],  R(d) = E(d+L)
+//     (5 | L and 5 | W, so all of a thread's lags share the same chunk bases);
+//   * decisions are EXACT: the f32 metric (absolute error <= ~5e-6 x prefix-energy / window-energy) only filters.
+//     The first crossing is accepted from f32 when "M >= thr(1-EPS)" and "M >= thr(1+EPS)" first hold at the same lag;
+//     the peak is re-evaluated in f64 (wave 0, from the raw samples still in LDS; products of f32 are exact in f64) at
+//     every lag within 2 EPS of the f32 window maximum.  Lags whose error bound is not small (prefix energy > 20x
+//     window energy) are never trusted.  Frames the filter cannot settle (ambiguous crossing, > 4 peak candidates)
+//     go to a device-side list and are redone by the all-f64 kernel k_sc_tile.  Outputs equal the f64 oracle's.
+constexpr int SP_WG = 512, SP_C = 5, SP_N = SP_WG * SP_C; // 2560 samples per tile
+constexpr float SC_EPS = 1e-3f;         // relative guard band of the f32 filter around the threshold / the maximum
+constexpr float SC_UNSAFE_RATIO = 20.f; // prefix energy / window energy above which a lag is never trusted
+constexpr int SC_MAXCAND = 4;
+
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_d(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true); // out-of-range / masked lanes read 0
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the 64 lanes of a wavefront (lane 63 ends up with the wave total)
+__device__ __forceinline__ double wave_scan(double x) {
+    x += dpp_d<0x111, 0xF>(x); // row_shr:1
+    x += dpp_d<0x112, 0xF>(x); // row_shr:2
+    x += dpp_d<0x114, 0xF>(x); // row_shr:4
+    x += dpp_d<0x118, 0xF>(x); // row_shr:8
+    x += dpp_d<0x142, 0xA>(x); // row_bcast:15 into rows 1 and 3
+    x += dpp_d<0x143, 0xC>(x); // row_bcast:31 into rows 2 and 3
+    return x;
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_s(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float wave_scan_f(float x) {
+    x += dpp_s<0x111, 0xF>(x);
+    x += dpp_s<0x112, 0xF>(x);
+    x += dpp_s<0x114, 0xF>(x);
+    x += dpp_s<0x118, 0xF>(x);
+    x += dpp_s<0x142, 0xA>(x);
+    x += dpp_s<0x143, 0xC>(x);
+    return x;
+}
+__device__ __forceinline__ float readlane_f(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+__device__ __forceinline__ double readlane_d(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+// Workgroup barrier that does NOT drain the VM counter: the next tile's LDS-DMA stays in flight across it.
+// (__syncthreads() would emit s_waitcnt vmcnt(0) while a global_load_lds is outstanding.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One 1-KiB LDS-DMA piece: lane i copies 16 B from sbase + voff (per lane) to lds_byte_addr + 16 i.  Issued from
+// inline asm so that hipcc does not count it and drain it with vmcnt(0) before the next ds_read; the kernel waits
+// for it by hand (s_waitcnt vmcnt(0) at the top of the frame loop).
+__device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char *)p);
+}
+
+struct ScRec { double pr, pi, num, den; }; // exact sums at the chosen lag (finish kernel turns them into CFO / metric)
+
+struct ScFastParams {
+    const float2 *in;
+    long long n_frames, frame_stride;
+    int n16;        // 16-byte pieces to stage per frame = min(SP_N, frame_len) / 2
+    int n_lags, L, W;
+    float thr_lo, thr_hi;
+    double thr;
+    int32_t *d_hat;
+    ScRec *rec;
+    int32_t *slow_list; // frames the filter could not settle
+    int32_t *slow_count;
+};
+
+__global__ __launch_bounds__(SP_WG, 4) void k_sc_fast(ScFastParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int L = p.L, W = p.W, n = p.n_lags;
+    const int rspan = SP_N + L; // raw slab (entries past the staged samples are never used by a valid lag)
+    cf *raw0 = reinterpret_cast<cf *>(smem);
+    cf *raw1 = raw0 + rspan;
+    float2 *lq = reinterpret_cast<float2 *>(raw1 + rspan); // [SP_N] exclusive local prefix of q
+    float2 *bq = lq + SP_N;                                // [SP_WG] chunk bases
+    float *le = reinterpret_cast<float *>(bq + SP_WG);     // [SP_N] exclusive local prefix of e
+    float *be = le + SP_N;                                 // [SP_WG]
+    float *wtot = be + SP_WG;                              // [8][4] wave totals (qr, qi, e, -)
+    int *sh = reinterpret_cast<int *>(wtot + 32);          // [2][8] per-parity: lo, hi, max bits, count, cand[4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cL = L / SP_C, cW = W / SP_C;
+    const unsigned raw_lds[2] = {lds_addr(raw0), lds_addr(raw1)};
+    const int n0 = tid * SP_C;
+    const bool has_samples = n0 < 2 * p.n16; // threads past the staged samples contribute zeros
+    const bool live = n0 < n;                // this thread owns at least one searched lag
+
+    long long f = blockIdx.x;
+    const long long fstep = gridDim.x;
+    // stage(frame, buffer): 1-KiB pieces dealt round-robin to the 8 waves
+    auto stage = [&](long long fr, int bufi) {
+        const char *sbase = reinterpret_cast<const char *>(p.in + fr * p.frame_stride);
+        for (int piece = wave; piece * 64 < p.n16; piece += SP_WG / 64) {
+            const int i = piece * 64 + lane;
+            if (i < p.n16) glds16(sbase, (unsigned)i * 16u, raw_lds[bufi] + (unsigned)piece * 1024u);
+        }
+    };
+    if (f < p.n_frames) stage(f, 0);
+    if (tid < 16) sh[tid] = (tid & 7) < 2 ? INT_MAX : 0;
+    int cur = 0;
+
+    for (; f < p.n_frames; f += fstep, cur ^= 1) {
+        const cf *raw = cur ? raw1 : raw0;
+        int *S = sh + cur * 8;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
+        lds_barrier();                                   // ... and everyone else's; previous frame fully consumed
+        if (f + fstep < p.n_frames) stage(f + fstep, cur ^ 1);
+        if (tid < 8) sh[(cur ^ 1) * 8 + tid] = tid < 2 ? INT_MAX : 0; // reset the other parity's slots (idle since last frame)
+
+        // ---- phase 1 (f32): products once per sample, exclusive local prefixes to LDS, own copies in registers
+        float2 oq[SP_C];
+        float oe[SP_C];
+        float rqr = 0.f, rqi = 0.f, re = 0.f;
+        if (has_samples) {
+            cf a[SP_C], b[SP_C];
+#pragma unroll
+            for (int j = 0; j < SP_C; ++j) { a[j] = raw[n0 + j]; b[j] = raw[n0 + j + L]; }
+#pragma unroll
+            for (int j = 0; j < SP_C; ++j) {
+                oq[j] = make_float2(rqr, rqi);
+                oe[j] = re;
+                lq[n0 + j] = oq[j];
+                le[n0 + j] = re;
+                rqr += a[j].x * b[j].x + a[j].y * b[j].y;
+                rqi += a[j].x * b[j].y - a[j].y * b[j].x;
+                re += a[j].x * a[j].x + a[j].y * a[j].y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SP_C; ++j) { oq[j] = make_float2(0.f, 0.f); oe[j] = 0.f; }
+        }
+        const float iqr = wave_scan_f(rqr), iqi = wave_scan_f(rqi), ie = wave_scan_f(re);
+        if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
+        lds_barrier();
+        // exclusive prefix of the 8 wave totals: lanes 0..7 hold one total each, 3 DPP steps, broadcast by readlane
+        float wq = lane < 8 ? wtot[lane * 4 + 0] : 0.f, wi = lane < 8 ? wtot[lane * 4 + 1] : 0.f,
+              we = lane < 8 ? wtot[lane * 4 + 2] : 0.f;
+        float sq = wq, si = wi, se = we;
+        sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
+        sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
+        sq += dpp_s<0x114, 0xF>(sq); si += dpp_s<0x114, 0xF>(si); se += dpp_s<0x114, 0xF>(se);
+        const float mybqr = (iqr - rqr) + (readlane_f(sq, wave) - readlane_f(wq, wave));
+        const float mybqi = (iqi - rqi) + (readlane_f(si, wave) - readlane_f(wi, wave));
+        const float mybe = (ie - re) + (readlane_f(se, wave) - readlane_f(we, wave));
+        bq[tid] = make_float2(mybqr, mybqi);
+        be[tid] = mybe;
+        lds_barrier();
+
+        // ---- phase 2A (f32): metric at this thread's 5 lags; threshold-crossing candidates
+        float mr[SP_C];      // f32 metric, -1 where the lag is not searched / has no energy
+        unsigned force = 0u; // lags whose f32 error bound is too large to trust
+#pragma unroll
+        for (int j = 0; j < SP_C; ++j) mr[j] = -1.f;
+        if (live) { // implies tid + cW + cL < SP_WG
+            const float2 b1 = bq[tid + cW];
+            const float dBqr = b1.x - mybqr, dBqi = b1.y - mybqi;
+            const float etop = be[tid + cW + cL];
+            const float dBe = be[tid + cW] - mybe, dBr = etop - be[tid + cL];
+            float2 q1[SP_C];
+            float e1[SP_C], e2[SP_C], e3[SP_C];
+#pragma unroll
+            for (int j = 0; j < SP_C; ++j) {
+                q1[j] = lq[n0 + j + W];
+                e1[j] = le[n0 + j + W];
+                e2[j] = le[n0 + j + W + L];
+                e3[j] = le[n0 + j + L];
+            }
+            int lo = INT_MAX, hi = INT_MAX;
+#pragma unroll
+            for (int j = SP_C - 1; j >= 0; --j) {
+                const float pr = (q1[j].x - oq[j].x) + dBqr, pi = (q1[j].y - oq[j].y) + dBqi;
+                const float E = (e1[j] - oe[j]) + dBe, R = (e2[j] - e3[j]) + dBr;
+                const float den = E * R;
+                const bool ok = (n0 + j < n) && den > 0.f;
+                const float m = (pr * pr + pi * pi) * __builtin_amdgcn_rcpf(den);
+                mr[j] = ok ? m : -1.f;
+                const bool unsafe = ok && etop > SC_UNSAFE_RATIO * fminf(E, R);
+                if (unsafe) force |= 1u << j;
+                if (ok && (unsafe || m >= p.thr_lo)) lo = n0 + j;
+                if (ok && !unsafe && m >= p.thr_hi) hi = n0 + j;
+            }
+            if (lo != INT_MAX) atomicMin(&S[0], lo);
+            if (hi != INT_MAX) atomicMin(&S[1], hi);
+        }
+        lds_barrier();
+        const int c_lo = S[0], c_hi = S[1];
+        if (c_lo == INT_MAX) { // nothing reaches the threshold (exactly): no packet
+            if (tid == 0) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, 1.0}; }
+            continue;
+        }
+        if (c_lo != c_hi) { // the f32 filter cannot place the first crossing: redo this frame in f64
+            if (tid == 0) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, -1.0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; }
+            continue;
+        }
+        const int d1 = c_lo;
+        // ---- peak candidates: lags of [d1, d1 + W] within 2 EPS of the f32 window maximum, or untrusted
+        const bool inwin = live && n0 + SP_C > d1 && n0 <= d1 + W;
+        unsigned wmask = 0u;
+        if (inwin) {
+            float mloc = 0.f;
+#pragma unroll
+            for (int j = 0; j < SP_C; ++j) {
+                const int d = n0 + j;
+                if (d >= d1 && d <= d1 + W && mr[j] >= 0.f) {
+                    wmask |= 1u << j;
+                    if (!((force >> j) & 1u)) mloc = fmaxf(mloc, mr[j]);
+                }
+            }
+            if (mloc > 0.f) atomicMax(reinterpret_cast<unsigned *>(&S[2]), __float_as_uint(mloc));
+        }
+        lds_barrier();
+        if (inwin) {
+            const float mcut = __uint_as_float((unsigned)S[2]) * (1.f - 2.f * SC_EPS);
+#pragma unroll
+            for (int j = 0; j < SP_C; ++j) {
+                if (((wmask >> j) & 1u) && (((force >> j) & 1u) || mr[j] >= mcut)) {
+                    const int slot = atomicAdd(&S[3], 1);
+                    if (slot < SC_MAXCAND) S[4 + slot] = n0 + j;
+                }
+            }
+        }
+        lds_barrier();
+        // ---- exact decision by wave 0 only (the other waves move on and wait at the next frame's barrier)
+        if (wave == 0) {
+            const int cnt = S[3];
+            if (cnt > SC_MAXCAND || cnt <= 0) {
+                if (lane == 0) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, -1.0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; }
+            } else {
+                Cand best = Cand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
+                for (int i = 0; i < cnt; ++i) {
+                    const int d = S[4 + i];
+                    double xr = 0, xi = 0, xe = 0, xq = 0;
+                    for (int m = lane; m < W; m += 64) {
+                        const cf a = raw[d + m], b = raw[d + m + L];
+                        const double ar = a.x, ai = a.y, br = b.x, bi = b.y;
+                        xr += ar * br + ai * bi;
+                        xi += ar * bi - ai * br;
+                        xe += ar * ar + ai * ai;
+                        xq += br * br + bi * bi;
+                    }
+                    xr = readlane_d(wave_scan(xr), 63); xi = readlane_d(wave_scan(xi), 63);
+                    xe = readlane_d(wave_scan(xe), 63); xq = readlane_d(wave_scan(xq), 63);
+                    const double xn = xr * xr + xi * xi, xd = xe * xq;
+                    // first maximum wins: strictly greater, or equal at a lower lag (candidates arrive unordered)
+                    if (xd > 0.0) {
+                        const double lhs = xn * best.den, rhs = best.num * xd;
+                        if (lhs > rhs || (lhs == rhs && d < best.lag)) best = Cand{xn, xd, xr, xi, d};
+                    }
+                }
+                if (lane == 0) {
+                    if (best.lag == INT_MAX) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, 1.0}; }
+                    else { p.d_hat[f] = best.lag; p.rec[f] = ScRec{best.pr, best.pi, best.num, best.den}; }
+                }
+            }
+        }
+    }
+}
+
+// CFO and metric from the exact sums (one thread per frame; slow frames are finished by k_sc_tile instead)
+__global__ __launch_bounds__(256) void k_sc_finish(const ScRec *rec, long long n_frames, int L, double *f_delta, float *metric) {
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_frames) return;
+    const ScRec r = rec[f];
+    if (r.den < 0.0) return; // deferred to the exact kernel
+    const bool found = r.num > 0.0;
+    if (f_delta) f_delta[f] = found ? atan2(r.pi, r.pr) / (double)L : 0.0;
+    if (metric) metric[f] = found ? (float)(r.num / r.den) : 0.f;
+}
+
+size_t sc_fast_lds_bytes(int L) {
+    return (size_t)2 * (SP_N + L) * sizeof(float2) + (size_t)SP_N * (sizeof(float2) + sizeof(float)) +
+           (size_t)SP_WG * (sizeof(float2) + sizeof(float)) + 32 * sizeof(float) + 16 * sizeof(int) + 16;
+}
+bool sc_fast_ok(const ScParams &p) {
+    // one tile per frame, short period (at least 1280 lags per tile), 5 | L, 16-byte aligned even-length frames
+    return p.mode == 0 && p.L % SP_C == 0 && p.W % SP_C == 0 && (SP_N - p.W - p.L) >= SP_N / 2 &&
+           p.n_lags <= (SP_N - p.W - p.L) && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (p.frame_stride & 1) == 0 &&
+           (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L) <= 80 * 1024;
+}
+size_t sc_fast_workspace_bytes(long long n_frames) { return (size_t)n_frames * (sizeof(ScRec) + sizeof(int32_t)) + 64; }
+
+// p.mode == 0, p.tiles_per_frame == 1.  workspace: sc_fast_workspace_bytes(n_frames) bytes of device memory.
+hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st) {
+    if (p.n_frames <= 0) return hipSuccess;
+    const size_t lds = sc_fast_lds_bytes(p.L);
+    static bool attr_set[64] = {false}; // per device, once: the call is not free and sits on the launch path
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sc_fast),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    ScRec *rec = reinterpret_cast<ScRec *>(workspace);
+    int32_t *slow_count = reinterpret_cast<int32_t *>(rec + p.n_frames);
+    int32_t *slow_list = slow_count + 4;
+    hipError_t e = hipMemsetAsync(slow_count, 0, 16, st);
+    if (e != hipSuccess) return e;
+    ScFastParams q;
+    q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride;
+    const long long stage = p.frame_len < SP_N ? p.frame_len : SP_N;
+    q.n16 = (int)(stage / 2);
+    q.n_lags = (int)p.n_lags; q.L = p.L; q.W = p.W;
+    q.thr = p.threshold;
+    q.thr_lo = (float)(p.threshold * (1.0 - (double)SC_EPS));
+    q.thr_hi = (float)(p.threshold * (1.0 + (double)SC_EPS));
+    q.d_hat = p.d_hat; q.rec = rec; q.slow_list = slow_list; q.slow_count = slow_count;
+    long long grid = (long long)num_cu * 2; // two workgroups per CU (LDS-bound), persistent over the frame list
+    if (grid > p.n_frames) grid = p.n_frames;
+    hipLaunchKernelGGL(k_sc_fast, dim3((unsigned)grid), dim3(SP_WG), lds, st, q);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, rec, p.n_frames, p.L,
+                       p.f_delta, p.metric);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // frames the filter could not settle: all-f64 kernel over the device-side list (usually empty)
+    ScParams s = p;
+    s.slow_list = slow_list; s.slow_count = slow_count; s.tiles_per_frame = 1; s.mode = 0;
+    const size_t lds2 = sc_lds_bytes(s);
+    if (lds2 > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sc_tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+    }
+    long long g2 = p.n_frames < 512 ? p.n_frames : 512;
+    hipLaunchKernelGGL(k_sc_tile, dim3((unsigned)g2), dim3(SC_WG), lds2, st, s);
+    return hipGetLastError();
+}
 
 __global__ void k_sc_min_cross(const long long *cross, int tiles, long long n_frames, int32_t *d1) {
     long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -408,15 +408,24 @@ static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame
     p.in = in; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len; p.n_lags = n_lags;
     p.L = L; p.W = W; p.threshold = (double)c->prm.sync_threshold;
     p.d_hat = d_hat; p.f_delta = f_delta; p.metric = metric;
+    // one-tile frames with a short period: f32 filter + exact f64 decisions (k_sc_fast)
+    p.tiles_per_frame = 1; p.mode = 0;
+    if (sc_fast_ok(p)) {
+        void *wsp;
+        int rc = ws_get(c, 6, sc_fast_workspace_bytes(n_frames), &wsp);
+        if (rc) return rc;
+        HIP_TRY(c, run_sc_fast(p, wsp, c->num_cu, c->stream));
+        return OFDM_OK;
+    }
     if (sc_lds_bytes(p) > 160 * 1024) return OFDM_ERR_UNSUPPORTED; // window does not fit one CU's LDS
     const int CH = sc_tile_lags();
     const int64_t tiles = (n_lags + CH - 1) / CH;
+    if (tiles > 0x7fffffff) return OFDM_ERR_INVALID;
     if (tiles == 1) {
-        p.tiles_per_frame = 1; p.mode = 0;
         HIP_TRY(c, run_sc(p, c->stream));
         return OFDM_OK;
     }
-    if (tiles > 0x7fffffff) return OFDM_ERR_INVALID;
+    // long captures: first threshold crossing per tile -> per frame -> peak search from there (one tile)
     void *cross, *d1;
     int rc = ws_get(c, 6, sizeof(long long) * (size_t)(n_frames * tiles), &cross);
     if (rc) return rc;

@@ -209,6 +209,26 @@ def test_sc_correlate_batch(api, orc):
         assert host(d2)[f] == orc.sc_sync(wide(caps[f][:2000]), 80, 3, 256, 0.5)[0]
 
 
+def test_sc_correlate_untrusted_f32_filter(api, orc):
+    # A strong burst ahead of the frame makes the prefix energy >> window energy, so the fast kernel's f32 filter must
+    # not be trusted there: those frames are redone by the all-f64 kernel (device-side slow list).  Results still exact.
+    rng = np.random.default_rng(12)
+    caps = []
+    for f in range(24):
+        payload = bytes(rng.integers(0, 256, 560, dtype=np.uint8))
+        c, _ = make_capture(orc, rng, orc.QAM64, True, payload, 2176, int(rng.integers(20, 60)), 0.01, 30.0)
+        c = c.copy()
+        if f % 2 == 0:
+            c[2:14] += fc32(40.0 * (rng.standard_normal(12) + 1j * rng.standard_normal(12)))
+        caps.append(c)
+    caps = np.stack(caps)
+    ctx = api.Context(modulation=api.QAM64, guard_bands=True)
+    d_hat, f_delta, metric = (host(t) for t in ctx.sc_correlate(dev(ctx, caps)))
+    for f in range(24):
+        wd, _, wm, wfd = orc.sc_sync(wide(caps[f]), 80, 3, 0, 0.5)
+        assert d_hat[f] == wd and abs(f_delta[f] - wfd) <= 1e-9 and abs(metric[f] - wm) <= 1e-6, f"frame {f}"
+
+
 def test_sc_correlate_long_capture_multi_tile(api, orc):
     # one long capture (jetson_rx style): the frame sits past several 2560-lag tiles, odd start
     rng = np.random.default_rng(6)
