@@ -88,16 +88,11 @@ def main():
     import numpy as np
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    from ofdm_amd.dist import Group
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    grp = Group()  # torch.distributed over RCCL when launched by torchrun; a no-op single rank otherwise
+    world, rank, local = grp.world, grp.rank, grp.local
+    dist = grp.dist
     n_gpus = world
     if a.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
@@ -116,8 +111,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        grp.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -130,10 +124,7 @@ def main():
     ev_ms = ctx.timer_stop_ms()  # HIP events on the launch stream, spans exactly the K launches
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, ev_ms = float(t[0]), float(t[1])
+    dt, ev_ms = grp.reduce_max(dt, ev_ms)  # the slowest rank defines the step time
 
     # parity at full size through a size-independent property: decoded bytes == transmitted payload (BER)
     nerr = int((out != payload).any(dim=1).sum())
@@ -141,14 +132,21 @@ def main():
     bits = 0
     for sh in range(8):
         bits += int(((diff >> sh) & 1).sum())
-    ber = bits / (F * payload.shape[1] * 8)
+    bits, nerr = (int(v) for v in grp.reduce_sum(bits, nerr))
+    ber = bits / (n_gpus * F * payload.shape[1] * 8)
 
     samples_per_step = F * syms * ctx.S
     value = n_gpus * samples_per_step * a.steps / dt / 1e6
     kern_s = ev_ms / 1e3 / a.steps
     alg_bytes = F * (syms * ctx.S * 8 + syms * ctx.bytes_per_symbol)  # 8 B/sample read + packed bytes written
-    roof = {"bound": "hbm", "kernel": "k_sym<64,DEMOD>", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+    traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), scaled to F
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["k_demod64"]
+        traffic = F * (pm["read_bytes_per_frame"] + pm["write_bytes_per_frame"])
+    except Exception:
+        pass
+    roof = {"bound": "hbm", "kernel": "ofdm::k_demod64<6, true, false>", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes}
 
     res = {
@@ -188,9 +186,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(res))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

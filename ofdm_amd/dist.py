@@ -1,0 +1,86 @@
+"""Frame-index data parallelism: one process per GPU, no collective on the data path.
+
+Frames are independent (decode is a pure function of its samples, src/receiver.rs:9-96), so rank r of R simply
+owns a contiguous frame range; results are concatenated by the host.  torch.distributed (RCCL on GPUs, gloo on
+CPU in the tests) is used only for the timing barrier and the max-over-ranks reduction that bench.py reports.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+
+def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split: rank r gets [r*F/R, (r+1)*F/R); sizes differ by at most one frame."""
+    if world <= 0 or not (0 <= rank < world) or n_frames < 0:
+        raise ValueError("bad shard request")
+    return (n_frames * rank) // world, (n_frames * (rank + 1)) // world
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(world_size, rank, local_rank) from the torchrun environment (1, 0, 0 when launched plainly)."""
+    return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+class Group:
+    """Thin wrapper over torch.distributed for the bench / tests: barrier, max and sum of a few scalars, gather."""
+
+    def __init__(self, backend: Optional[str] = None, device=None):
+        import torch
+
+        self.torch = torch
+        self.world, self.rank, self.local = env_world()
+        self.dist = None
+        self.device = device
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            kw = {}
+            if backend == "nccl":
+                torch.cuda.set_device(self.local)
+                kw["device_id"] = torch.device("cuda", self.local)
+                self.device = torch.device("cuda", self.local)
+            if not dist.is_initialized():
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+            self.dist = dist
+        if self.device is None:
+            self.device = torch.device("cpu")
+
+    def barrier(self):
+        if self.torch.cuda.is_available() and self.device.type == "cuda":
+            self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def reduce_max(self, *vals: float):
+        if self.dist is None:
+            return list(vals)
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def reduce_sum(self, *vals: float):
+        if self.dist is None:
+            return list(vals)
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t]
+
+    def gather_bytes(self, payload: bytes):
+        """All ranks' byte strings in rank order (rank 0 only; others get None).  Off the timed path."""
+        if self.dist is None:
+            return [payload]
+        out = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(payload, out, dst=0)
+        return out
+
+    def close(self):
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None

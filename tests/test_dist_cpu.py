@@ -1,0 +1,66 @@
+"""Multi-rank path on CPU: world_size-2 gloo.  Frames are index-split across ranks with no data-path collective
+(SURVEY.md 8e); the only communication is the timing barrier / max reduction and an off-path gather.  The per-shard
+worker here is the CPU oracle (tests may use it); the property checked is that the sharded result equals the
+single-process result byte for byte."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_exactly():
+    from ofdm_amd.dist import shard_range
+
+    for n in (0, 1, 7, 8, 1000, 1_000_003):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_range(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as orc
+    from ofdm_amd.dist import Group, shard_range
+    from util import make_symbols, wide
+
+    g = Group(backend="gloo")
+    assert (g.world, g.rank) == (world, rank)
+    rng = np.random.default_rng(123)                      # every rank regenerates the same batch ...
+    x, data = make_symbols(orc, rng, 24 * 4, 64, True, orc.QAM64, snr_db=32.0)
+    frames = x.reshape(24, 4 * 80)
+    lo, hi = shard_range(24, rank, world)                 # ... and decodes only its own frame range
+    g.barrier()
+    mine = orc.rx_demod(wide(frames[lo:hi].reshape(-1)), 64, True, orc.QAM64)
+    tmax, = g.reduce_max(float(rank + 1))                 # the bench's max-over-ranks timing reduction
+    total, = g.reduce_sum(float(hi - lo))
+    parts = g.gather_bytes(mine)
+    if rank == 0:
+        q.put((b"".join(parts), data, tmax, total))
+    g.close()
+
+
+def test_two_rank_index_split_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    joined, data, tmax, total = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert joined == data          # concatenated shards == the whole batch decoded in one piece
+    assert tmax == 2.0 and total == 24.0

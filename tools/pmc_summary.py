@@ -1,0 +1,13 @@
+"""Summarise a rocprofv3 counter_collection.csv: mean counter value per dispatch for the ofdm:: kernels."""
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in sys.argv[1:]:
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            name = row.get("Kernel_Name", "")
+            if "ofdm::" not in name:
+                continue
+            acc[name.split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, d in sorted(acc.items()):
+    for c, vals in sorted(d.items()):
+        print(f"{k}\t{c}\tcalls={len(vals)}\tmean={sum(vals)/len(vals):.1f}")
