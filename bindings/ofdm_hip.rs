@@ -1,0 +1,157 @@
+//! bindings/ofdm_hip.rs -- Rust FFI for libofdm_hip.so (include/ofdm_hip.h).
+//!
+//! UNTESTED SOURCE TEXT: the authoring image has no cargo/rustc.  It shows the binding a
+//! maintainer of jkelleyrtp/ofdm would add as `src/ofdm_hip.rs` so that `encode` / `decode`
+//! (src/transmitter.rs:11-58, src/receiver.rs:9-96) keep their signatures while the DSP runs on an MI355X.
+#![allow(non_camel_case_types, dead_code)]
+use num::complex::Complex64;
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct ofdm_ctx { _private: [u8; 0] }
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct ofdm_fc32 { pub re: f32, pub im: f32 }
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct ofdm_params {
+    pub n_fft: i32, pub cp_len: i32, pub modulation: i32, pub guard_bands: i32, pub ecc: i32,
+    pub sync_window_reps: i32, pub sync_backoff: i32, pub cfo_mode: i32, pub sync_threshold: f32,
+    pub reserved: [i32; 7],
+}
+
+pub const OFDM_OK: c_int = 0;
+pub const OFDM_FRAME_SHORT: i32 = -1; // "Input not long enough, bailing early" (src/receiver.rs:27-29)
+pub const OFDM_MOD_BPSK: i32 = 1;
+pub const OFDM_MOD_QPSK: i32 = 2;
+pub const OFDM_MOD_QAM64: i32 = 6;
+
+#[link(name = "ofdm_hip")]
+extern "C" {
+    pub fn ofdm_abi_version() -> c_int;
+    pub fn ofdm_strerror(status: c_int) -> *const c_char;
+    pub fn ofdm_device_count(count: *mut c_int) -> c_int;
+    pub fn ofdm_default_params(p: *mut ofdm_params) -> c_int;
+    pub fn ofdm_default_pilots(n_fft: i32, cp_len: i32, preamble: *mut f64, training: *mut f64) -> c_int;
+    pub fn ofdm_create(p: *const ofdm_params, preamble: *const f64, training: *const f64, device: c_int,
+                       stream: *mut c_void, out: *mut *mut ofdm_ctx) -> c_int;
+    pub fn ofdm_destroy(ctx: *mut ofdm_ctx) -> c_int;
+    pub fn ofdm_set_stream(ctx: *mut ofdm_ctx, stream: *mut c_void) -> c_int;
+    pub fn ofdm_synchronize(ctx: *mut ofdm_ctx) -> c_int;
+    pub fn ofdm_last_hip_error(ctx: *const ofdm_ctx) -> c_int;
+    pub fn ofdm_dev_alloc(ctx: *mut ofdm_ctx, bytes: usize, dev: *mut *mut c_void) -> c_int;
+    pub fn ofdm_dev_free(ctx: *mut ofdm_ctx, dev: *mut c_void) -> c_int;
+    pub fn ofdm_memcpy_h2d(ctx: *mut ofdm_ctx, dev: *mut c_void, host: *const c_void, bytes: usize) -> c_int;
+    pub fn ofdm_memcpy_d2h(ctx: *mut ofdm_ctx, host: *mut c_void, dev: *const c_void, bytes: usize) -> c_int;
+    pub fn ofdm_memset(ctx: *mut ofdm_ctx, dev: *mut c_void, value: c_int, bytes: usize) -> c_int;
+    pub fn ofdm_symbol_len(ctx: *const ofdm_ctx) -> c_int;
+    pub fn ofdm_data_carriers(ctx: *const ofdm_ctx) -> c_int;
+    pub fn ofdm_bytes_per_symbol(ctx: *const ofdm_ctx) -> c_int;
+    pub fn ofdm_coded_len(ctx: *const ofdm_ctx, payload_bytes: i64) -> i64;
+    pub fn ofdm_data_symbols(ctx: *const ofdm_ctx, payload_bytes: i64) -> i64;
+    pub fn ofdm_frame_samples(ctx: *const ofdm_ctx, payload_bytes: i64) -> i64;
+    pub fn ofdm_fft_batch(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, out_dev: *mut ofdm_fc32, n_vec: i64, inverse: c_int) -> c_int;
+    pub fn ofdm_ifft_cp_batch(ctx: *mut ofdm_ctx, freq_dev: *const ofdm_fc32, out_dev: *mut ofdm_fc32, n_sym: i64) -> c_int;
+    pub fn ofdm_unprefix_batch(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, out_dev: *mut ofdm_fc32, n_sym: i64) -> c_int;
+    pub fn ofdm_qam_map_batch(ctx: *mut ofdm_ctx, bytes_dev: *const u8, n_bytes: i64, out_dev: *mut ofdm_fc32) -> c_int;
+    pub fn ofdm_qam_demap_batch(ctx: *mut ofdm_ctx, sym_dev: *const ofdm_fc32, n_sym: i64, bytes_dev: *mut u8, idx_dev: *mut u8) -> c_int;
+    pub fn ofdm_encode_block_batch(ctx: *mut ofdm_ctx, data_dev: *const ofdm_fc32, bins_dev: *mut ofdm_fc32, n_sym: i64) -> c_int;
+    pub fn ofdm_normalize_batch(ctx: *mut ofdm_ctx, x_dev: *mut ofdm_fc32, n_frames: i64, frame_stride: i64, frame_len: i64) -> c_int;
+    pub fn ofdm_hamming74_encode(ctx: *mut ofdm_ctx, in_dev: *const u8, n_bytes: i64, out_dev: *mut u8) -> c_int;
+    pub fn ofdm_hamming74_decode(ctx: *mut ofdm_ctx, in_dev: *const u8, n_bytes: i64, out_dev: *mut u8, corrected_dev: *mut u32) -> c_int;
+    pub fn ofdm_sc_correlate_batch(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, n_frames: i64, frame_stride: i64, frame_len: i64,
+                                   n_lags: i64, d_hat_dev: *mut i32, f_delta_dev: *mut f64, metric_dev: *mut f32) -> c_int;
+    pub fn ofdm_frequency_correction_batch(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, n_pairs: i64, stride: i64,
+                                           right_offset: i64, f_delta_dev: *mut f64) -> c_int;
+    pub fn ofdm_cfo_rotate_batch(ctx: *mut ofdm_ctx, x_dev: *mut ofdm_fc32, n_frames: i64, frame_stride: i64, frame_len: i64,
+                                 f_delta_dev: *const f64, first_index_dev: *const i32) -> c_int;
+    pub fn ofdm_estimate_channel_batch(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, n_frames: i64, frame_stride: i64,
+                                       frame_len: i64, offset_dev: *const i32, f_delta_dev: *const f64, hk_dev: *mut ofdm_fc32) -> c_int;
+    pub fn ofdm_rx_demod_batch(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, n_frames: i64, frame_stride: i64, frame_len: i64,
+                               first_symbol: i32, syms_per_frame: i32, offset_dev: *const i32, f_delta_dev: *const f64,
+                               hk_dev: *const ofdm_fc32, hk_stride: i64, out_dev: *mut u8, out_stride: i64, soft_dev: *mut ofdm_fc32) -> c_int;
+    pub fn ofdm_tx_encode_batch(ctx: *mut ofdm_ctx, payload_dev: *const u8, n_frames: i64, payload_stride: i64,
+                                payload_len_dev: *const i32, payload_bytes: i32, out_dev: *mut ofdm_fc32, out_stride: i64) -> c_int;
+    pub fn ofdm_rx_decode_batch(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, n_frames: i64, frame_stride: i64, frame_len: i64,
+                                n_lags: i64, max_symbols: i32, out_dev: *mut u8, out_stride: i64, out_len_dev: *mut i32,
+                                status_dev: *mut i32, offset_dev: *mut i32, f_delta_dev: *mut f64, metric_dev: *mut f32) -> c_int;
+    pub fn ofdm_timer_start(ctx: *mut ofdm_ctx) -> c_int;
+    pub fn ofdm_timer_stop_ms(ctx: *mut ofdm_ctx, elapsed_ms: *mut f32) -> c_int;
+}
+
+/// Owning wrapper: one context per (thread, GPU).
+pub struct Ctx { raw: *mut ofdm_ctx, s: usize, bytes_per_symbol: usize }
+
+fn check(rc: c_int, what: &str) -> anyhow::Result<()> {
+    if rc == OFDM_OK { Ok(()) } else {
+        let msg = unsafe { std::ffi::CStr::from_ptr(ofdm_strerror(rc)) }.to_string_lossy().into_owned();
+        Err(anyhow::anyhow!("{}: {}", what, msg))
+    }
+}
+
+impl Ctx {
+    pub fn new(guard_bands: bool, modulation: i32) -> anyhow::Result<Self> {
+        let mut p: ofdm_params = unsafe { std::mem::zeroed() };
+        check(unsafe { ofdm_default_params(&mut p) }, "ofdm_default_params")?;
+        p.guard_bands = guard_bands as i32;
+        p.modulation = modulation;
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { ofdm_create(&p, std::ptr::null(), std::ptr::null(), 0, std::ptr::null_mut(), &mut raw) }, "ofdm_create")?;
+        let s = unsafe { ofdm_symbol_len(raw) } as usize;
+        let bps = unsafe { ofdm_bytes_per_symbol(raw) } as usize;
+        Ok(Ctx { raw, s, bytes_per_symbol: bps })
+    }
+    fn alloc(&self, bytes: usize) -> anyhow::Result<*mut c_void> {
+        let mut d = std::ptr::null_mut();
+        check(unsafe { ofdm_dev_alloc(self.raw, bytes, &mut d) }, "ofdm_dev_alloc")?;
+        Ok(d)
+    }
+}
+impl Drop for Ctx { fn drop(&mut self) { unsafe { ofdm_destroy(self.raw); } } }
+
+/// `ofdm::encode!(data, guard_bands, modulation)` -- src/transmitter.rs:10-58
+pub fn encode(data: &[u8], guard_bands: Option<bool>, modulation: Option<i32>) -> anyhow::Result<Vec<Complex64>> {
+    let ctx = Ctx::new(guard_bands.unwrap_or(false), modulation.unwrap_or(OFDM_MOD_BPSK))?;
+    let n = unsafe { ofdm_frame_samples(ctx.raw, data.len() as i64) } as usize;
+    let d_in = ctx.alloc(data.len().max(1))?;
+    let d_out = ctx.alloc(n * 8)?;
+    unsafe {
+        check(ofdm_memcpy_h2d(ctx.raw, d_in, data.as_ptr() as *const c_void, data.len()), "h2d")?;
+        check(ofdm_tx_encode_batch(ctx.raw, d_in as *const u8, 1, data.len() as i64, std::ptr::null(), data.len() as i32,
+                                   d_out as *mut ofdm_fc32, n as i64), "ofdm_tx_encode_batch")?;
+        let mut host = vec![ofdm_fc32 { re: 0.0, im: 0.0 }; n];
+        check(ofdm_memcpy_d2h(ctx.raw, host.as_mut_ptr() as *mut c_void, d_out, n * 8), "d2h")?;
+        ofdm_dev_free(ctx.raw, d_in);
+        ofdm_dev_free(ctx.raw, d_out);
+        Ok(host.iter().map(|c| Complex64::new(c.re as f64, c.im as f64)).collect()) // bytes_to_sig, src/utils.rs:238-254
+    }
+}
+
+/// `ofdm::decode!(samples, guard_bands, modulation)` -- src/receiver.rs:8-96
+pub fn decode(samples: Vec<Complex64>, guard_bands: Option<bool>, modulation: Option<i32>) -> anyhow::Result<Vec<u8>> {
+    let ctx = Ctx::new(guard_bands.unwrap_or(false), modulation.unwrap_or(OFDM_MOD_BPSK))?;
+    let n = samples.len();
+    let fc32: Vec<ofdm_fc32> = samples.iter().map(|c| ofdm_fc32 { re: c.re as f32, im: c.im as f32 }).collect(); // sig_to_bytes
+    let max_sym = (((n + ctx.s - 1) / ctx.s).saturating_sub(10)).max(1);
+    let out_bytes = max_sym * ctx.bytes_per_symbol;
+    let (d_in, d_out, d_meta) = (ctx.alloc(n * 8)?, ctx.alloc(out_bytes)?, ctx.alloc(8)?);
+    unsafe {
+        check(ofdm_memcpy_h2d(ctx.raw, d_in, fc32.as_ptr() as *const c_void, n * 8), "h2d")?;
+        check(ofdm_rx_decode_batch(ctx.raw, d_in as *const ofdm_fc32, 1, n as i64, n as i64, 0, max_sym as i32,
+                                   d_out as *mut u8, out_bytes as i64, d_meta as *mut i32, (d_meta as *mut i32).add(1),
+                                   std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut()), "ofdm_rx_decode_batch")?;
+        let mut meta = [0i32; 2];
+        check(ofdm_memcpy_d2h(ctx.raw, meta.as_mut_ptr() as *mut c_void, d_meta, 8), "d2h")?;
+        let (len, status) = (meta[0] as usize, meta[1]);
+        let mut bytes = vec![0u8; len];
+        if status == 0 { check(ofdm_memcpy_d2h(ctx.raw, bytes.as_mut_ptr() as *mut c_void, d_out, len), "d2h")?; }
+        for d in [d_in, d_out, d_meta] { ofdm_dev_free(ctx.raw, d); }
+        match status {
+            0 => Ok(bytes),
+            OFDM_FRAME_SHORT => Err(anyhow::anyhow!("Input not long enough, bailing early")),
+            s => Err(anyhow::anyhow!("decode failed (frame status {})", s)),
+        }
+    }
+}
