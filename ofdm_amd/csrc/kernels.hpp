@@ -55,6 +55,8 @@ struct Fast64Params {
     int k0 = 0, blk_dk = 0, wave_dk = 0, step_dk = 0;
 };
 hipError_t run_demod64_fast(const SymParams &p, hipStream_t st, int num_cu);
+// fused estimate_channel + per-symbol demod for N = 64 frames with per-frame offset / CFO / live-symbol count
+hipError_t run_rxframe64(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu);
 
 hipError_t run_fft(int n, const SymParams &p, bool inverse, hipStream_t st, int num_cu);
 hipError_t run_ifft_cp(int n, const SymParams &p, hipStream_t st, int num_cu);

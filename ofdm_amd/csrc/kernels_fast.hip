@@ -135,6 +135,178 @@ __global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_rxframe64: the per-frame RX body for N = 64 after timing (BASELINE config 3): for every frame, one wavefront does
+//   estimate_channel (src/receiver.rs:212-229) on the 5 training blocks  -> 1/H kept in registers
+//   then per group of 8 data symbols: CFO derotation (receiver.rs:44-50, phase reduced in f64), CP strip + FFT64
+//   (receiver.rs:99-104), equalise (receiver.rs:68-70), pilot phase (receiver.rs:106-145), hard demap + LSB-first packing
+//   (receiver.rs:147-190).  Frames may start at any sample offset (8-byte aligned loads), samples at or beyond
+//   frame_len read as zero (pad_chunk).  No workgroup barrier: the 4 waves of a workgroup own 4 different frames.
+struct RxFrame64Params {
+    const float2 *in;
+    long long n_frames, frame_stride, frame_len;
+    const int32_t *offset;
+    const double *f_delta;
+    const int32_t *nsym;       // live data symbols per frame (0 = skip)
+    const float2 *tw, *inv_training;
+    unsigned char *out;        // raw decoded bytes, nsym * bytes_per_symbol per frame
+    long long out_stride;
+    float2 *hk;                // optional: channel estimate per frame (64 bins)
+};
+
+__device__ __forceinline__ cf lane_xor_sum(cf v) { // sum over the 8 symbol slots: lanes with equal (lane & 7)
+    v.x += dpp_f<0x128>(v.x); v.y += dpp_f<0x128>(v.y);          // row_ror:8  : lane ^ 8
+    v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64);
+    v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64);
+    return v;
+}
+
+template <int BPS, bool GUARD>
+__global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
+    constexpr int S = 80, CP = 16;
+    constexpr int ND = GUARD ? 48 : 64;
+    constexpr int SYM_BYTES = ND * BPS / 8;   // multiple of 4 (checked by the launcher)
+    constexpr int REGION_DW = ND * BPS / 4;   // 8 symbols
+    constexpr int SLAB = 8 * 72;
+    __shared__ cf slab_all[4 * SLAB];
+    __shared__ unsigned img_all[4 * REGION_DW];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = lane >> 3, t = lane & 7;
+    cf *buf = slab_all + wave * SLAB + s * 72;
+    unsigned *img = img_all + wave * REGION_DW;
+
+    cf w[7];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) w[r - 1] = p.tw[r * t];
+    int bitoff[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int c = t + 8 * m;
+        const int q = GUARD ? data_classes_below64(c) : c;
+        bitoff[m] = (carrier_class64(c, GUARD) == 0) ? (s * ND + q) * BPS : -1;
+    }
+    const int wr = swz(8 * t);
+
+    for (long long f = (long long)blockIdx.x * 4 + wave; f < p.n_frames; f += (long long)gridDim.x * 4) {
+        const int ns = p.nsym[f];
+        if (ns <= 0) continue; // wave-uniform
+        const long long off = p.offset ? p.offset[f] : 0;
+        const double turns = p.f_delta ? p.f_delta[f] * 0.15915494309189533577 : 0.0;
+        const cf st = cfo_phasor(turns, 8);
+        const cf *src = p.in + f * p.frame_stride + off;
+        const long long avail = p.frame_len - off; // samples of the trimmed frame
+
+        // group -1 = the 5 training blocks (chunks 5..9) -> 1/H; groups 0.. = data symbols, 8 at a time (chunks 10..)
+        cf g[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) g[m] = make_float2(1.f, 0.f);
+        for (int k0 = -8; k0 < ns; k0 += 8) {
+            const bool chest = k0 < 0;
+            const int count = chest ? 5 : (ns - k0 < 8 ? ns - k0 : 8);
+            const int n0 = ((chest ? 5 : 10 + k0) + s) * S + CP + t; // sample id of this lane's first point
+            cf v[8];
+            const int first_chunk = chest ? 5 : 10 + k0;
+            const bool all_inside = (long long)(first_chunk + count) * S <= avail; // wave-uniform: no tail padding in this group
+            if (s < count) {
+                if (all_inside) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) v[m] = src[n0 + 8 * m];
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) v[m] = (n0 + 8 * m) < avail ? src[n0 + 8 * m] : make_float2(0.f, 0.f);
+                }
+                if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50)
+                    cf ph = cfo_phasor(turns, n0);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
+            }
+            bfly8<false>(v);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+            bfly8<false>(v);
+            if (chest) { // estimate_channel: H = mean_b FFT(block_b) / training  (receiver.rs:212-229)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    cf h = lane_xor_sum(cmul(v[m], p.inv_training[t + 8 * m])); // 64-entry table, L2/L1 resident
+                    h = make_float2(h.x * 0.2f, h.y * 0.2f);
+                    if (p.hk && s == 0) p.hk[f * 64 + t + 8 * m] = h;
+                    const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
+                    g[m] = make_float2(h.x * rn, -h.y * rn); // 1 / H
+                }
+                continue;
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], g[m]); // equalise (receiver.rs:68-70)
+            if (GUARD) {
+                cf pv = make_float2(1.f, 0.f);
+                pv = (t == 6) ? v[0] : pv;
+                pv = (t == 1) ? v[3] : pv;
+                pv = (t == 7) ? v[4] : pv;
+                pv = (t == 2) ? v[7] : pv;
+                const float ang = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.25f;
+                float sn, cs;
+                sincospif(ang, &sn, &cs);
+                const cf rot = make_float2(cs, -sn);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
+            }
+            for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (bitoff[m] >= 0) {
+                    const unsigned idx = demap_point(v[m], BPS);
+                    const int wd = bitoff[m] >> 5, sh = bitoff[m] & 31;
+                    atomicOr(&img[wd], idx << sh);
+                    if (BPS > 1 && (32 % BPS) != 0) {
+                        if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
+                    }
+                }
+            }
+            unsigned *dst = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k0 * SYM_BYTES);
+            const int ndw = count * (SYM_BYTES / 4);
+            for (int i = lane; i < ndw; i += 64) dst[i] = img[i];
+        }
+    }
+}
+
+template <int BPS> static hipError_t launch_rxframe(const RxFrame64Params &p, bool guard, dim3 grid, hipStream_t st) {
+    if (guard) hipLaunchKernelGGL((k_rxframe64<BPS, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_rxframe64<BPS, false>), grid, dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// Fused channel estimate + demod for N = 64 frames.  hipErrorNotSupported => caller uses run_chest + run_demod.
+hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, int num_cu) {
+    const int nd = sp.guard ? 48 : 64;
+    if ((nd * sp.bps / 8) % 4 != 0 || !sp.nsym_frame || sp.soft) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
+    if (sp.n_frames <= 0) return hipSuccess;
+    RxFrame64Params p;
+    p.in = sp.in; p.n_frames = sp.n_frames; p.frame_stride = sp.frame_stride; p.frame_len = sp.frame_len;
+    p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym = sp.nsym_frame; p.tw = sp.tw; p.inv_training = sp.inv_training;
+    p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.hk = hk_out;
+    long long blocks = (sp.n_frames + 3) / 4, cap = (long long)num_cu * 8;
+    const dim3 grid((unsigned)(blocks < cap ? blocks : cap));
+    switch (sp.bps) {
+    case 2: return launch_rxframe<2>(p, sp.guard != 0, grid, st);
+    case 4: return launch_rxframe<4>(p, sp.guard != 0, grid, st);
+    case 6: return launch_rxframe<6>(p, sp.guard != 0, grid, st);
+    case 8: return launch_rxframe<8>(p, sp.guard != 0, grid, st);
+    case 1: if (!sp.guard) return launch_rxframe<1>(p, false, grid, st); return hipErrorNotSupported;
+    default: return hipErrorNotSupported;
+    }
+}
+
 template <int BPS> static hipError_t launch_bps(const Fast64Params &p, bool guard, dim3 grid, hipStream_t st) {
     const bool hk = p.hk != nullptr;
     if (guard && hk) hipLaunchKernelGGL((k_demod64<BPS, true, true>), grid, dim3(256), 0, st, p);

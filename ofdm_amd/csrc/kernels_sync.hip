@@ -231,7 +231,7 @@ int sc_tile_lags() { return SC_CH; }
 //     every lag within 2 EPS of the f32 window maximum.  Lags whose error bound is not small (prefix energy > 20x
 //     window energy) are never trusted.  Frames the filter cannot settle (ambiguous crossing, > 4 peak candidates)
 //     go to a device-side list and are redone by the all-f64 kernel k_sc_tile.  Outputs equal the f64 oracle's.
-constexpr int SP_WG = 512, SP_C = 5, SP_N = SP_WG * SP_C; // 2560 samples per tile
+constexpr int SP_C = 5; // samples (and lags) per thread; the tile holds 5 * WG samples (WG = 128, 256 or 512 threads)
 constexpr float SC_EPS = 1e-3f;         // relative guard band of the f32 filter around the threshold / the maximum
 constexpr float SC_UNSAFE_RATIO = 20.f; // prefix energy / window energy above which a lag is never trusted
 constexpr int SC_MAXCAND = 4;
@@ -302,7 +302,9 @@ struct ScFastParams {
     int32_t *slow_count;
 };
 
-__global__ __launch_bounds__(SP_WG, 4) void k_sc_fast(ScFastParams p) {
+template <int SP_WG>
+__global__ __launch_bounds__(SP_WG, (SP_WG == 512 ? 4 : 2)) void k_sc_fast(ScFastParams p) {
+    constexpr int SP_N = SP_WG * SP_C, NW = SP_WG / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     const int L = p.L, W = p.W, n = p.n_lags;
     const int rspan = SP_N + L; // raw slab (entries past the staged samples are never used by a valid lag)
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(SP_WG, 4) void k_sc_fast(ScFastParams p) {
     float2 *bq = lq + SP_N;                                // [SP_WG] chunk bases
     float *le = reinterpret_cast<float *>(bq + SP_WG);     // [SP_N] exclusive local prefix of e
     float *be = le + SP_N;                                 // [SP_WG]
-    float *wtot = be + SP_WG;                              // [8][4] wave totals (qr, qi, e, -)
+    float *wtot = be + SP_WG;                              // [NW][4] wave totals (qr, qi, e, -)
     int *sh = reinterpret_cast<int *>(wtot + 32);          // [2][8] per-parity: lo, hi, max bits, count, cand[4]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -371,8 +373,8 @@ __global__ __launch_bounds__(SP_WG, 4) void k_sc_fast(ScFastParams p) {
         if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
         lds_barrier();
         // exclusive prefix of the 8 wave totals: lanes 0..7 hold one total each, 3 DPP steps, broadcast by readlane
-        float wq = lane < 8 ? wtot[lane * 4 + 0] : 0.f, wi = lane < 8 ? wtot[lane * 4 + 1] : 0.f,
-              we = lane < 8 ? wtot[lane * 4 + 2] : 0.f;
+        float wq = lane < NW ? wtot[lane * 4 + 0] : 0.f, wi = lane < NW ? wtot[lane * 4 + 1] : 0.f,
+              we = lane < NW ? wtot[lane * 4 + 2] : 0.f;
         float sq = wq, si = wi, se = we;
         sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
         sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
@@ -505,28 +507,39 @@ __global__ __launch_bounds__(256) void k_sc_finish(const ScRec *rec, long long n
     if (metric) metric[f] = found ? (float)(r.num / r.den) : 0.f;
 }
 
-size_t sc_fast_lds_bytes(int L) {
-    return (size_t)2 * (SP_N + L) * sizeof(float2) + (size_t)SP_N * (sizeof(float2) + sizeof(float)) +
-           (size_t)SP_WG * (sizeof(float2) + sizeof(float)) + 32 * sizeof(float) + 16 * sizeof(int) + 16;
+static size_t sc_fast_lds_bytes(int L, int wg) {
+    const size_t n = (size_t)wg * SP_C;
+    return (size_t)2 * (n + L) * sizeof(float2) + n * (sizeof(float2) + sizeof(float)) +
+           (size_t)wg * (sizeof(float2) + sizeof(float)) + 32 * sizeof(float) + 16 * sizeof(int) + 16;
+}
+// smallest workgroup (128 / 256 / 512 threads, 5 samples each) whose tile covers the searched lags plus the window
+static int sc_fast_pick_wg(const ScParams &p) {
+    static const int min_wg = [] { const char *e = getenv("OFDM_SC_MIN_WG"); return e ? atoi(e) : 256; }(); // tuning knob (the 128-thread variant is not validated yet)
+    for (int wg = min_wg; wg <= 512; wg *= 2)
+        if ((long long)wg * SP_C - p.W - p.L >= p.n_lags) return wg;
+    return 0;
 }
 bool sc_fast_ok(const ScParams &p) {
-    // one tile per frame, short period (at least 1280 lags per tile), 5 | L, 16-byte aligned even-length frames
-    return p.mode == 0 && p.L % SP_C == 0 && p.W % SP_C == 0 && (SP_N - p.W - p.L) >= SP_N / 2 &&
-           p.n_lags <= (SP_N - p.W - p.L) && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (p.frame_stride & 1) == 0 &&
-           (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L) <= 80 * 1024;
+    // one tile per frame, 5 | L, 16-byte aligned even-length frames, LDS for two 512-thread workgroups per CU
+    const int wg = sc_fast_pick_wg(p);
+    return p.mode == 0 && wg != 0 && p.L % SP_C == 0 && p.W % SP_C == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 &&
+           (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L, wg) <= 80 * 1024;
 }
 size_t sc_fast_workspace_bytes(long long n_frames) { return (size_t)n_frames * (sizeof(ScRec) + sizeof(int32_t)) + 64; }
 
 // p.mode == 0, p.tiles_per_frame == 1.  workspace: sc_fast_workspace_bytes(n_frames) bytes of device memory.
 hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st) {
     if (p.n_frames <= 0) return hipSuccess;
-    const size_t lds = sc_fast_lds_bytes(p.L);
+    const int wg = sc_fast_pick_wg(p);
+    const size_t lds = sc_fast_lds_bytes(p.L, wg);
     static bool attr_set[64] = {false}; // per device, once: the call is not free and sits on the launch path
     int dev = 0;
     hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sc_fast),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sc_fast<512>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sc_fast<256>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
@@ -537,16 +550,22 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     if (e != hipSuccess) return e;
     ScFastParams q;
     q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride;
-    const long long stage = p.frame_len < SP_N ? p.frame_len : SP_N;
+    const long long tile_n = (long long)wg * SP_C;
+    const long long stage = p.frame_len < tile_n ? p.frame_len : tile_n;
     q.n16 = (int)(stage / 2);
     q.n_lags = (int)p.n_lags; q.L = p.L; q.W = p.W;
     q.thr = p.threshold;
     q.thr_lo = (float)(p.threshold * (1.0 - (double)SC_EPS));
     q.thr_hi = (float)(p.threshold * (1.0 + (double)SC_EPS));
     q.d_hat = p.d_hat; q.rec = rec; q.slow_list = slow_list; q.slow_count = slow_count;
-    long long grid = (long long)num_cu * 2; // two workgroups per CU (LDS-bound), persistent over the frame list
+    // persistent over the frame list; workgroups per CU are LDS-bound (2 x 512, 4 x 256, 7 x 128 threads)
+    long long per_cu = (long long)(160 * 1024) / (long long)lds;
+    if (per_cu > 2048 / wg) per_cu = 2048 / wg;
+    long long grid = (long long)num_cu * per_cu;
     if (grid > p.n_frames) grid = p.n_frames;
-    hipLaunchKernelGGL(k_sc_fast, dim3((unsigned)grid), dim3(SP_WG), lds, st, q);
+    if (wg == 512) hipLaunchKernelGGL(k_sc_fast<512>, dim3((unsigned)grid), dim3(512), lds, st, q);
+    else if (wg == 256) hipLaunchKernelGGL(k_sc_fast<256>, dim3((unsigned)grid), dim3(256), lds, st, q);
+    else hipLaunchKernelGGL(k_sc_fast<128>, dim3((unsigned)grid), dim3(128), lds, st, q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, rec, p.n_frames, p.L,
                        p.f_delta, p.metric);

@@ -565,17 +565,27 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     // 2. trimmed start, length check, live symbols (receiver.rs:21-36)
     HIP_TRY(c, run_rx_prepare(n_frames, (const int32_t *)w_dhat, fd, frame_len, c->S(), c->prm.sync_backoff,
                               c->prm.cfo_mode, max_symbols, bps_bytes, status, offs, (int32_t *)w_nsym, c->stream));
-    // 3. channel estimate from the 5 training blocks, CFO-derotated (receiver.rs:44-56)
-    {
+    // 3+4. channel estimate from the 5 training blocks and per data symbol CP strip + FFT + equalise + pilot phase +
+    //      demap (receiver.rs:44-83).  N = 64: one fused wave-centric kernel; otherwise the generic pair.
+    bool fused = false;
+    if (N == 64) {
+        SymParams p = base_params(c);
+        p.in = x; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
+        p.offset = offs; p.f_delta = fd; p.nsym_frame = (const int32_t *)w_nsym;
+        p.out_bytes = (uint8_t *)w_raw; p.out_stride = raw_stride;
+        hipError_t e = run_rxframe64(p, nullptr, c->stream, c->num_cu);
+        if (e == hipSuccess) fused = true;
+        else if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
+    }
+    if (!fused) {
         SymParams p = base_params(c);
         p.in = x; p.out = (float2 *)w_hk; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
         p.offset = offs; p.f_delta = fd;
         HIP_TRY(c, run_chest(N, p, c->stream, c->num_cu));
+        rc = demod_run(c, x, n_frames, frame_stride, frame_len, 10, max_symbols, offs, fd, (const int32_t *)w_nsym,
+                       (const float2 *)w_hk, N, (uint8_t *)w_raw, raw_stride, nullptr);
+        if (rc) return rc;
     }
-    // 4. per data symbol: CP strip + FFT + equalise + pilot phase + demap (receiver.rs:64-83)
-    rc = demod_run(c, x, n_frames, frame_stride, frame_len, 10, max_symbols, offs, fd, (const int32_t *)w_nsym,
-                   (const float2 *)w_hk, N, (uint8_t *)w_raw, raw_stride, nullptr);
-    if (rc) return rc;
     // 5. length header, truncate [, Hamming decode] (receiver.rs:85-95)
     HIP_TRY(c, run_rx_finish((const uint8_t *)w_raw, raw_stride, n_frames, status, (const int32_t *)w_nsym, bps_bytes,
                              c->prm.ecc, out, out_stride, out_len, c->stream));
