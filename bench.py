@@ -92,6 +92,8 @@ def main():
 
     grp = Group()  # torch.distributed over RCCL when launched by torchrun; a no-op single rank otherwise
     world, rank, local = grp.world, grp.rank, grp.local
+    if "OFDM_FORCE_DEVICE" in os.environ:  # rehearsal of the N-rank flow on a one-GPU box (with OFDM_DIST_BACKEND=gloo)
+        local = int(os.environ["OFDM_FORCE_DEVICE"])
     dist = grp.dist
     n_gpus = world
     if a.gpus != world and rank == 0 and world > 1:

@@ -38,8 +38,8 @@ class Group:
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend is None:  # RCCL on GPUs; OFDM_DIST_BACKEND=gloo rehearses the multi-rank flow on one GPU / on CPU
+                backend = os.environ.get("OFDM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             kw = {}
             if backend == "nccl":
                 torch.cuda.set_device(self.local)

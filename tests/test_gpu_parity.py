@@ -392,3 +392,76 @@ def test_loopback_lab3_on_gpu(api, orc, timing_error):
     got = api.decode(rx, False, api.QPSK, cfo_mode=api.CFO_ABS)
     assert got == data
     assert orc.analysis(data, got) == (0, 0, 0.0)
+
+
+# ------------------------------------------------------------------ size-independent properties at large sizes
+def test_large_batch_properties(api, orc):
+    """Properties that need no oracle run, at sizes far beyond what the oracle finishes in seconds:
+    TX -> RX round trip is the identity on bytes, two independent kernels (wave-centric fast path and the generic
+    Stockham kernel) agree bit for bit, FFT linearity, and Schmidl-Cox timing is shift-equivariant."""
+    import torch
+    ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
+    g = torch.Generator(device=ctx.device); g.manual_seed(7)
+    F, syms = 65536, 16
+    nb = syms * ctx.bytes_per_symbol
+    pay = torch.randint(0, 256, (F * nb,), dtype=torch.uint8, device=ctx.device, generator=g)
+    x = ctx.prefix_block(ctx.encode_block(ctx.modulate(pay).view(-1, ctx.data_carriers))).view(F, syms * 80)
+    x = x + torch.view_as_complex(torch.randn((F, syms * 80, 2), device=ctx.device, generator=g) * 0.001)  # sigma 0.008 per bin after the FFT: 18 sigma to a boundary
+    fast = ctx.rx_demod(x, syms_per_frame=syms)                                  # k_demod64 (syms % 8 == 0)
+    assert torch.equal(fast.view(-1), pay)                                       # round trip: BER 0
+    generic = ctx.rx_demod(x.view(F * 4, 4 * 80), syms_per_frame=4)              # k_sym<64, DEMOD>
+    assert torch.equal(generic.view(-1), fast.view(-1))                          # checksum of checksums: all bytes
+    # linearity of the batched FFT at 1M vectors
+    a = torch.view_as_complex(torch.randn((1 << 20, 64, 2), device=ctx.device, generator=g))
+    b = torch.view_as_complex(torch.randn((1 << 20, 64, 2), device=ctx.device, generator=g))
+    lhs = ctx.fft(a + 2 * b)
+    rhs = ctx.fft(a) + 2 * ctx.fft(b)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max()) < 1e-5
+    assert float((ctx.fft(ctx.fft(a), inverse=True) - a).abs().max()) < 1e-4    # ifft(fft(x)) == x
+    # Schmidl-Cox: delaying the capture by k samples moves d_hat by k (same CFO, same metric)
+    rng = np.random.default_rng(3)
+    tx = orc.encode(bytes(rng.integers(0, 256, 560, dtype=np.uint8)), True, orc.QAM64)
+    base = through_channel(orc, rng, tx, 2176, 10, 0.02, 30.0)
+    shifts = np.arange(0, 40, 2)
+    caps = np.stack([np.concatenate([np.zeros(k, np.complex64), base[: 2176 - k]]) for k in shifts])
+    d, fd, m = (host(t) for t in ctx.sc_correlate(dev(ctx, caps)))
+    assert np.array_equal(d - d[0], shifts) and np.abs(fd - fd[0]).max() < 1e-6
+
+
+def test_edge_cases(api, orc):
+    import torch
+    # empty payload: header only (one data symbol), on both sides of the link
+    for mod, guard in ((api.BPSK, False), (api.QAM64, True)):
+        ctx = api.Context(modulation=mod, guard_bands=guard)
+        frames = ctx.encode_batch(torch.zeros((2, 0), dtype=torch.uint8, device=ctx.device))
+        want = orc.encode(b"", guard, mod)
+        assert frames.shape[1] == want.size and rel_err(host(frames)[0], want) <= TOL
+        cap = np.concatenate([np.zeros(7, np.complex64), host(frames)[0], np.zeros(120, np.complex64)])
+        res = ctx.decode_batch(dev(ctx, cap).reshape(1, -1), max_symbols=ctx.data_symbols(0))
+        assert int(res["status"][0]) == 0 and int(res["len"][0]) == 0
+        short = ctx.decode_batch(dev(ctx, cap).reshape(1, -1), max_symbols=1)  # BPSK: 8 bytes/symbol < 16-byte header
+        assert int(short["status"][0]) == (api.FRAME_HEADER if mod == api.BPSK else 0)
+    # ragged batch: frames of different true length in equal slots -> per-frame status / length
+    ctx = api.Context(modulation=api.QPSK)
+    rng = np.random.default_rng(9)
+    slot = 4000
+    caps, pays = [], []
+    for n in (0, 1, 100, 400, 399):
+        pay = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        tx = orc.encode(pay, False, orc.QPSK)
+        caps.append(through_channel(orc, rng, tx, slot, 5, 0.01, 35.0)); pays.append(pay)
+    caps.append(fc32(0.01 * (rng.standard_normal(slot) + 1j * rng.standard_normal(slot)))); pays.append(None)   # noise only
+    caps.append(np.concatenate([caps[3][:900], np.zeros(slot - 900, np.complex64)])); pays.append(None)             # truncated
+    res = ctx.decode_batch(dev(ctx, np.stack(caps)), max_symbols=40, frame_len=slot)
+    st, ln = host(res["status"]), host(res["len"])
+    for f, pay in enumerate(pays):
+        w = orc.decode_sc(wide(caps[f]), False, orc.QPSK, max_symbols=40)
+        assert st[f] == w["status"], f
+        if pay is not None:
+            assert st[f] == 0 and ln[f] == len(pay) and bytes(host(res["bytes"])[f][: ln[f]]) == pay == w["bytes"]
+    assert st[5] == api.FRAME_NOSYNC
+    # maximum supported transform and the widest constellation through the whole chain once
+    ctx = api.Context(n_fft=4096, modulation=api.QAM256, guard_bands=True)
+    pay = rng.integers(0, 256, (1, 9000), dtype=np.uint8)
+    frames = host(ctx.encode_batch(torch.from_numpy(pay).to(ctx.device)))
+    assert rel_err(frames[0], orc.encode(bytes(pay[0]), True, orc.QAM256, 4096)) <= TOL

@@ -43,10 +43,10 @@ def cfg4(n_frames=8192, steps=5):
     x = torch.zeros((n_frames, span), dtype=torch.complex64, device="cuda")
     x[:, 100:100 + frames.shape[1]] = frames
     x += torch.view_as_complex(torch.randn((n_frames, span, 2), device="cuda", generator=g) * 1e-4)
-    res = ctx.decode_batch(x, max_symbols=D, n_lags=512)
+    res = ctx.decode_batch(x, max_symbols=D, n_lags=2048)
     torch.cuda.synchronize()
     ctx.timer_start()
-    for _ in range(steps): res = ctx.decode_batch(x, max_symbols=D, n_lags=512)
+    for _ in range(steps): res = ctx.decode_batch(x, max_symbols=D, n_lags=2048)
     ms = ctx.timer_stop_ms() / steps
     ok = (res["status"] == 0) & (res["len"] >= nbytes)
     good = int(((res["bytes"][:, :nbytes] == pay).all(dim=1) & ok).sum())
