@@ -79,8 +79,9 @@ template <int N> struct Plan {
     static constexpr int G = WG / T;                // symbols per workgroup iteration
     static constexpr int LDS_SYM = N + 8;           // per-symbol LDS stride (pad 8 points: conflict-free reads)
     static constexpr bool WAVE_LOCAL = (T <= 64);   // a symbol's threads live in one wavefront: no barriers
-    // twiddle registers: 7 per radix-8 pass after the first, 6 per radix-4 pass
-    static constexpr int NTW = (A8 - 1) * 7 + B4 * 6;
+    // twiddle registers: ONE base twiddle per radix-8 pass after the first, two per radix-4 pass (one per butterfly);
+    // the powers w^2 .. w^7 are formed by successive multiplication (<= 7 roundings, ~4e-7 relative)
+    static constexpr int NTW = (A8 - 1) + B4 * 2;
     __host__ __device__ static constexpr int radix(int p) { return p < A8 ? 8 : 4; }
 };
 
@@ -101,17 +102,12 @@ template <int N> __device__ __forceinline__ void load_twiddles(const cf *__restr
 #pragma unroll
     for (int p = 1; p < P::PASSES; ++p) {
         if (P::radix(p) == 8) {
-            int k = t % ns, step = N / (ns * 8);
-#pragma unroll
-            for (int r = 1; r < 8; ++r) w[wi++] = tw[r * k * step];
+            w[wi++] = tw[(t % ns) * (N / (ns * 8))];
             ns *= 8;
         } else {
-            int step = N / (ns * 4);
-            int ka = t % ns, kb = (t + P::T) % ns;
-#pragma unroll
-            for (int r = 1; r < 4; ++r) w[wi++] = tw[r * ka * step];
-#pragma unroll
-            for (int r = 1; r < 4; ++r) w[wi++] = tw[r * kb * step];
+            const int step = N / (ns * 4);
+            w[wi++] = tw[(t % ns) * step];
+            w[wi++] = tw[((t + P::T) % ns) * step];
             ns *= 4;
         }
     }
@@ -133,9 +129,11 @@ template <int N, bool INV> __device__ __forceinline__ void fft_symbol(cf *v, cf 
         }
         if (P::radix(p) == 8) {
             if (p > 0) {
+                const cf w1 = twid<INV>(w[wi]);
+                cf wr = w1;
 #pragma unroll
-                for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twid<INV>(w[wi + r - 1]));
-                wi += 7;
+                for (int r = 1; r < 8; ++r) { v[r] = cmul(v[r], wr); if (r < 7) wr = cmul(wr, w1); }
+                wi += 1;
             }
             bfly8<INV>(v);
             if (p < P::PASSES - 1) {
@@ -145,11 +143,17 @@ template <int N, bool INV> __device__ __forceinline__ void fft_symbol(cf *v, cf 
             }
             ns *= 8;
         } else {
+            {
+                const cf wa1 = twid<INV>(w[wi]), wb1 = twid<INV>(w[wi + 1]);
+                cf wa = wa1, wb = wb1;
 #pragma unroll
-            for (int r = 1; r < 4; ++r) v[2 * r] = cmul(v[2 * r], twid<INV>(w[wi + r - 1]));
-#pragma unroll
-            for (int r = 1; r < 4; ++r) v[2 * r + 1] = cmul(v[2 * r + 1], twid<INV>(w[wi + 3 + r - 1]));
-            wi += 6;
+                for (int r = 1; r < 4; ++r) {
+                    v[2 * r] = cmul(v[2 * r], wa);
+                    v[2 * r + 1] = cmul(v[2 * r + 1], wb);
+                    if (r < 3) { wa = cmul(wa, wa1); wb = cmul(wb, wb1); }
+                }
+            }
+            wi += 2;
             bfly4<INV>(v, 0);
             bfly4<INV>(v, 1);
             if (p < P::PASSES - 1) {

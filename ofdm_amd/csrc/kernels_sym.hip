@@ -57,13 +57,42 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
     const int c0 = t / K;        // reference carrier class of bin t + m*T is c0 + 8m
     const long long total = (MODE == M_CHEST) ? p.n_frames : p.n_frames * (long long)p.syms_per_frame;
 
+    // symbol index -> (frame, symbol in frame); 32-bit division whenever the batch allows it
+    const bool small = total < 0x7fffffffLL;
+    auto split = [&](long long sg, long long &f, int &k) {
+        if (small) { const unsigned q = (unsigned)sg / (unsigned)p.syms_per_frame; f = q; k = (int)((unsigned)sg - q * (unsigned)p.syms_per_frame); }
+        else { f = sg / p.syms_per_frame; k = (int)(sg - f * p.syms_per_frame); }
+    };
+    // first-pass loads of symbol sg in the Stockham pattern x[t + m*T] (zero past frame_len / past the batch)
+    auto fetch = [&](long long sg, cf *dst) {
+        if (sg < total) {
+            long long f; int k;
+            split(sg, f, k);
+            const long long off = p.offset ? p.offset[f] : 0;
+            const long long n0 = (long long)(p.first_symbol + k) * p.in_sym_stride + p.in_skip;
+            const cf *src = p.in + f * p.frame_stride;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                long long pos = off + n0 + t + m * T;
+                dst[m] = pos < p.frame_len ? src[pos] : make_float2(0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) dst[m] = make_float2(0.f, 0.f);
+        }
+    };
+    // software pipeline: the NEXT iteration's samples are in flight (8 x 8 B per lane) while this one runs its passes
+    constexpr bool PREFETCH = (MODE != M_CHEST && MODE != M_TX);
+    cf pre[8];
+    if (PREFETCH) fetch((long long)blockIdx.x * G + slot, pre);
+
     for (long long base = (long long)blockIdx.x * G; base < total; base += (long long)gridDim.x * G) {
         const long long sigma = base + slot;
         const bool valid = sigma < total;
         long long f = 0; int k = 0;
         if (valid) {
             if (MODE == M_CHEST) { f = sigma; }
-            else { f = sigma / p.syms_per_frame; k = (int)(sigma - f * p.syms_per_frame); }
+            else split(sigma, f, k);
         }
         cf v[8];
 
@@ -136,24 +165,17 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
             }
-        } else if (valid) {
-            const long long off = p.offset ? p.offset[f] : 0;
-            const long long n0 = (long long)(p.first_symbol + k) * p.in_sym_stride + p.in_skip;
-            const cf *src = p.in + f * p.frame_stride;
+        } else {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                long long pos = off + n0 + t + m * T;
-                v[m] = pos < p.frame_len ? src[pos] : make_float2(0.f, 0.f);
-            }
-            if (MODE == M_DEMOD && p.f_delta) {
+            for (int m = 0; m < 8; ++m) v[m] = pre[m];
+            fetch(base + (long long)gridDim.x * G + slot, pre); // issue the next symbol's loads now
+            if (MODE == M_DEMOD && p.f_delta && valid) {
+                const long long n0 = (long long)(p.first_symbol + k) * p.in_sym_stride + p.in_skip;
                 const double turns = p.f_delta[f] * 0.15915494309189533577; // 1/(2 pi)
                 cf ph = cfo_phasor(turns, n0 + t), st = cfo_phasor(turns, T);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
             }
-        } else {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
         }
         if (MODE == M_DEMOD && valid && p.nsym_frame && k >= p.nsym_frame[f]) {
             // this frame holds fewer symbols (short capture / failed sync): nothing is written for it

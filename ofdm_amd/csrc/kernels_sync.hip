@@ -294,6 +294,7 @@ struct ScFastParams {
     long long n_frames, frame_stride;
     int n16;        // 16-byte pieces to stage per frame = min(SP_N, frame_len) / 2
     int n_lags, L, W;
+    int debug;      // profiling aid (OFDM_SC_DEBUG): 1 = no staging after the first tile, 2 = stop after phase 1, 3 = after packet detect
     float thr_lo, thr_hi;
     double thr;
     int32_t *d_hat;
@@ -496,6 +497,219 @@ __global__ __launch_bounds__(SP_WG, (SP_WG == 512 ? 4 : 2)) void k_sc_fast(ScFas
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_sc_fast2: second-generation fast path (same "filter in f32, decide in f64" contract as k_sc_fast), shaped by
+// the counters of round 1 (a VALU op costs ~4 SIMD cycles; k_sc_fast waves were parked 52 % of the time):
+//   * 10 samples / lags per thread (256-thread workgroup per 2560-sample tile): per-thread overhead (scan, bases,
+//     candidate bookkeeping) is amortised over twice the samples and every LDS access is a 16- or 8-byte op;
+//   * the f32 prefix array of q ALIASES the raw tile (raw -> registers -> barrier -> prefixes), so a workgroup needs
+//     35 KB of LDS and FOUR independent workgroups share a CU: one group's barrier / DMA stalls hide behind the others;
+//   * the next frame's LDS-DMA is issued as soon as the prefixes are dead (after the packet-detect barrier);
+//   * the few exact f64 re-evaluations read their 2 x 240 samples back from global memory (L2 hits).
+__device__ __forceinline__ bool more_dbg(const ScFastParams &p, long long f, long long fstep) { return f + fstep < p.n_frames; }
+template <int WG>
+__global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
+    constexpr int C = 10, TN = WG * C, NW = WG / 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int L = p.L, W = p.W, n = p.n_lags;
+    cf *raw = reinterpret_cast<cf *>(smem);                 // [TN + L] raw tile ...
+    float2 *lq = reinterpret_cast<float2 *>(smem);          // ... later overwritten by [TN] exclusive local prefix of q
+    float *le = reinterpret_cast<float *>(raw + TN + L);    // [TN] exclusive local prefix of e
+    float2 *bq = reinterpret_cast<float2 *>(le + TN);       // [WG] chunk bases
+    float *be = reinterpret_cast<float *>(bq + WG);         // [WG]
+    float *wtot = be + WG;                                  // [NW][4] wave totals
+    int *sh = reinterpret_cast<int *>(wtot + 4 * NW);       // [2][8] per-parity: lo, hi, max bits, count, cand[4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cL = L / C, cW = W / C;
+    const unsigned raw_lds = lds_addr(raw);
+    const int n0 = tid * C;
+    const bool has_samples = n0 < 2 * p.n16;
+    const bool live = n0 < n; // this thread owns at least one searched lag (implies tid + cW + cL < WG)
+
+    auto stage = [&](long long fr) { // this wave's 1-KiB pieces of frame fr -> raw tile
+        const char *sbase = reinterpret_cast<const char *>(p.in + fr * p.frame_stride);
+        for (int piece = wave; piece * 64 < p.n16; piece += NW) {
+            const int i = piece * 64 + lane;
+            if (i < p.n16) glds16(sbase, (unsigned)i * 16u, raw_lds + (unsigned)piece * 1024u);
+        }
+    };
+    long long f = blockIdx.x;
+    const long long fstep = gridDim.x;
+    if (f < p.n_frames) stage(f);
+    if (tid < 16) sh[tid] = (tid & 7) < 2 ? INT_MAX : 0;
+    int cur = 0;
+
+    for (; f < p.n_frames; f += fstep, cur ^= 1) {
+        int *S = sh + cur * 8;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
+        lds_barrier();                                   // B0: ... and everyone else's
+        if (tid < 8) sh[(cur ^ 1) * 8 + tid] = tid < 2 ? INT_MAX : 0;
+        // ---- raw tile -> registers (16-byte LDS reads)
+        cf a[C], b[C];
+        if (has_samples) {
+            const float4 *pa = reinterpret_cast<const float4 *>(raw + n0), *pb = reinterpret_cast<const float4 *>(raw + n0 + L);
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) {
+                const float4 x = pa[i], y = pb[i];
+                a[2 * i] = make_float2(x.x, x.y); a[2 * i + 1] = make_float2(x.z, x.w);
+                b[2 * i] = make_float2(y.x, y.y); b[2 * i + 1] = make_float2(y.z, y.w);
+            }
+        }
+        lds_barrier(); // B1: every thread holds its samples, the raw tile may be overwritten by the prefixes
+        // ---- phase 1 (f32): products once per sample, exclusive local prefixes
+        float rqr = 0.f, rqi = 0.f, re = 0.f;
+        if (has_samples) {
+            float4 *wq4 = reinterpret_cast<float4 *>(lq + n0);
+            float2 *we2 = reinterpret_cast<float2 *>(le + n0);
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) { // two samples per step: one 16-byte and one 8-byte LDS store
+                const int j = 2 * i;
+                const float q0r = rqr, q0i = rqi, e0 = re;
+                rqr += a[j].x * b[j].x + a[j].y * b[j].y;
+                rqi += a[j].x * b[j].y - a[j].y * b[j].x;
+                re += a[j].x * a[j].x + a[j].y * a[j].y;
+                wq4[i] = make_float4(q0r, q0i, rqr, rqi);
+                we2[i] = make_float2(e0, re);
+                rqr += a[j + 1].x * b[j + 1].x + a[j + 1].y * b[j + 1].y;
+                rqi += a[j + 1].x * b[j + 1].y - a[j + 1].y * b[j + 1].x;
+                re += a[j + 1].x * a[j + 1].x + a[j + 1].y * a[j + 1].y;
+            }
+        }
+        const float iqr = wave_scan_f(rqr), iqi = wave_scan_f(rqi), ie = wave_scan_f(re);
+        if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
+        lds_barrier(); // B2
+        float wq = lane < NW ? wtot[lane * 4 + 0] : 0.f, wi = lane < NW ? wtot[lane * 4 + 1] : 0.f,
+              we = lane < NW ? wtot[lane * 4 + 2] : 0.f;
+        float sq = wq, si = wi, se = we;
+        sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
+        sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
+        const float mybqr = (iqr - rqr) + (readlane_f(sq, wave) - readlane_f(wq, wave));
+        const float mybqi = (iqi - rqi) + (readlane_f(si, wave) - readlane_f(wi, wave));
+        const float mybe = (ie - re) + (readlane_f(se, wave) - readlane_f(we, wave));
+        bq[tid] = make_float2(mybqr, mybqi);
+        be[tid] = mybe;
+        lds_barrier(); // B3
+        if (p.debug == 2) { if (more_dbg(p, f, fstep)) stage(f + fstep); continue; }
+
+        // ---- phase 2A (f32): metric at this thread's 10 lags; threshold-crossing candidates
+        float mr[C];
+        unsigned force = 0u;
+#pragma unroll
+        for (int j = 0; j < C; ++j) mr[j] = -1.f;
+        if (live) {
+            const float2 b1 = bq[tid + cW];
+            const float dBqr = b1.x - mybqr, dBqi = b1.y - mybqi;
+            const float etop = be[tid + cW + cL];
+            const float dBe = be[tid + cW] - mybe, dBr = etop - be[tid + cL];
+            const float4 *pq = reinterpret_cast<const float4 *>(lq + n0 + W), *pq0 = reinterpret_cast<const float4 *>(lq + n0);
+            const float2 *p1 = reinterpret_cast<const float2 *>(le + n0 + W), *p2 = reinterpret_cast<const float2 *>(le + n0 + W + L),
+                         *p3 = reinterpret_cast<const float2 *>(le + n0 + L), *p0 = reinterpret_cast<const float2 *>(le + n0);
+            int lo = INT_MAX, hi = INT_MAX;
+#pragma unroll
+            for (int i = C / 2 - 1; i >= 0; --i) {
+                const float4 q4 = pq[i], o4 = pq0[i];
+                const float2 x1 = p1[i], x2 = p2[i], x3 = p3[i], x0 = p0[i];
+#pragma unroll
+                for (int h = 1; h >= 0; --h) {
+                    const int j = 2 * i + h;
+                    const float q1x = h ? q4.z : q4.x, q1y = h ? q4.w : q4.y;
+                    const float e1 = h ? x1.y : x1.x, e2 = h ? x2.y : x2.x, e3 = h ? x3.y : x3.x;
+                    const float oqx = h ? o4.z : o4.x, oqy = h ? o4.w : o4.y, oe0 = h ? x0.y : x0.x;
+                    const float pr = (q1x - oqx) + dBqr, pi = (q1y - oqy) + dBqi;
+                    const float E = (e1 - oe0) + dBe, R = (e2 - e3) + dBr;
+                    const float den = E * R;
+                    const bool ok = (n0 + j < n) && den > 0.f;
+                    const float m = (pr * pr + pi * pi) * __builtin_amdgcn_rcpf(den);
+                    mr[j] = ok ? m : -1.f;
+                    const bool unsafe = ok && etop > SC_UNSAFE_RATIO * fminf(E, R);
+                    if (unsafe) force |= 1u << j;
+                    if (ok && (unsafe || m >= p.thr_lo)) lo = n0 + j;
+                    if (ok && !unsafe && m >= p.thr_hi) hi = n0 + j;
+                }
+            }
+            if (lo != INT_MAX) atomicMin(&S[0], lo);
+            if (hi != INT_MAX) atomicMin(&S[1], hi);
+        }
+        lds_barrier(); // B4: prefixes are dead from here on
+        const int c_lo = S[0], c_hi = S[1];
+        const bool more = f + fstep < p.n_frames;
+        if (more && wave != 0 && p.debug != 1) stage(f + fstep); // wave 0 stages after its exact phase (its global loads share the VM queue)
+        if (c_lo == INT_MAX || c_lo != c_hi) {
+            if (tid == 0) {
+                p.d_hat[f] = -1;
+                if (c_lo == INT_MAX) p.rec[f] = ScRec{0.0, 0.0, 0.0, 1.0};         // nothing reaches the threshold: no packet
+                else { p.rec[f] = ScRec{0.0, 0.0, 0.0, -1.0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; } // ambiguous: redo in f64
+            }
+            if (more && wave == 0 && p.debug != 1) stage(f + fstep);
+            continue;
+        }
+        const int d1 = c_lo;
+        // ---- peak candidates: lags of [d1, d1 + W] within 2 EPS of the f32 window maximum, or untrusted
+        const bool inwin = live && n0 + C > d1 && n0 <= d1 + W;
+        unsigned wmask = 0u;
+        if (inwin) {
+            float mloc = 0.f;
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const int d = n0 + j;
+                if (d >= d1 && d <= d1 + W && mr[j] >= 0.f) {
+                    wmask |= 1u << j;
+                    if (!((force >> j) & 1u)) mloc = fmaxf(mloc, mr[j]);
+                }
+            }
+            if (mloc > 0.f) atomicMax(reinterpret_cast<unsigned *>(&S[2]), __float_as_uint(mloc));
+        }
+        lds_barrier(); // B5
+        if (inwin) {
+            const float mcut = __uint_as_float((unsigned)S[2]) * (1.f - 2.f * SC_EPS);
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                if (((wmask >> j) & 1u) && (((force >> j) & 1u) || mr[j] >= mcut)) {
+                    const int slot = atomicAdd(&S[3], 1);
+                    if (slot < SC_MAXCAND) S[4 + slot] = n0 + j;
+                }
+            }
+        }
+        lds_barrier(); // B6
+        // ---- exact decision by wave 0 only, samples re-read from global memory (L2)
+        if (wave == 0) {
+            const int cnt = S[3];
+            if (cnt > SC_MAXCAND || cnt <= 0) {
+                if (lane == 0) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, -1.0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; }
+            } else {
+                const cf *src = p.in + f * p.frame_stride;
+                Cand best = Cand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
+                for (int i = 0; i < cnt; ++i) {
+                    const int d = S[4 + i];
+                    double xr = 0, xi = 0, xe = 0, xq = 0;
+                    for (int m = lane; m < W; m += 64) {
+                        const cf sa = src[d + m], sb = src[d + m + L];
+                        const double ar = sa.x, ai = sa.y, br = sb.x, bi = sb.y;
+                        xr += ar * br + ai * bi;
+                        xi += ar * bi - ai * br;
+                        xe += ar * ar + ai * ai;
+                        xq += br * br + bi * bi;
+                    }
+                    xr = readlane_d(wave_scan(xr), 63); xi = readlane_d(wave_scan(xi), 63);
+                    xe = readlane_d(wave_scan(xe), 63); xq = readlane_d(wave_scan(xq), 63);
+                    const double xn = xr * xr + xi * xi, xd = xe * xq;
+                    if (xd > 0.0) { // first maximum wins: strictly greater, or equal at a lower lag (candidates arrive unordered)
+                        const double lhs = xn * best.den, rhs = best.num * xd;
+                        if (lhs > rhs || (lhs == rhs && d < best.lag)) best = Cand{xn, xd, xr, xi, d};
+                    }
+                }
+                if (lane == 0) {
+                    if (best.lag == INT_MAX) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, 1.0}; }
+                    else { p.d_hat[f] = best.lag; p.rec[f] = ScRec{best.pr, best.pi, best.num, best.den}; }
+                }
+            }
+            if (more && p.debug != 1) stage(f + fstep);
+        }
+    }
+}
+
 // CFO and metric from the exact sums (one thread per frame; slow frames are finished by k_sc_tile instead)
 __global__ __launch_bounds__(256) void k_sc_finish(const ScRec *rec, long long n_frames, int L, double *f_delta, float *metric) {
     const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -507,23 +721,23 @@ __global__ __launch_bounds__(256) void k_sc_finish(const ScRec *rec, long long n
     if (metric) metric[f] = found ? (float)(r.num / r.den) : 0.f;
 }
 
-static size_t sc_fast_lds_bytes(int L, int wg) {
-    const size_t n = (size_t)wg * SP_C;
-    return (size_t)2 * (n + L) * sizeof(float2) + n * (sizeof(float2) + sizeof(float)) +
-           (size_t)wg * (sizeof(float2) + sizeof(float)) + 32 * sizeof(float) + 16 * sizeof(int) + 16;
+static size_t sc_fast_lds_bytes(int L, int wg) { // k_sc_fast2: raw tile (aliased by the q prefixes) + e prefixes + bases
+    const size_t n = (size_t)wg * 10;
+    return (n + L) * sizeof(float2) + n * sizeof(float) + (size_t)wg * (sizeof(float2) + sizeof(float)) +
+           16 * sizeof(float) * 2 + 16 * sizeof(int) + 16;
 }
-// smallest workgroup (128 / 256 / 512 threads, 5 samples each) whose tile covers the searched lags plus the window
+// smallest workgroup (128 / 256 threads, 10 samples each) whose tile covers the searched lags plus the window
 static int sc_fast_pick_wg(const ScParams &p) {
-    static const int min_wg = [] { const char *e = getenv("OFDM_SC_MIN_WG"); return e ? atoi(e) : 256; }(); // tuning knob (the 128-thread variant is not validated yet)
-    for (int wg = min_wg; wg <= 512; wg *= 2)
-        if ((long long)wg * SP_C - p.W - p.L >= p.n_lags) return wg;
+    static const int min_wg = [] { const char *e = getenv("OFDM_SC_MIN_WG"); return e ? atoi(e) : 128; }(); // tuning knob
+    for (int wg = min_wg; wg <= 256; wg *= 2)
+        if ((long long)wg * 10 - p.W - p.L >= p.n_lags) return wg;
     return 0;
 }
 bool sc_fast_ok(const ScParams &p) {
-    // one tile per frame, 5 | L, 16-byte aligned even-length frames, LDS for two 512-thread workgroups per CU
+    // one tile per frame, 10 | L, 16-byte aligned even-length frames
     const int wg = sc_fast_pick_wg(p);
-    return p.mode == 0 && wg != 0 && p.L % SP_C == 0 && p.W % SP_C == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 &&
-           (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L, wg) <= 80 * 1024;
+    return p.mode == 0 && wg != 0 && p.L % 10 == 0 && p.W % 10 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 &&
+           (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L, wg) <= 40 * 1024;
 }
 size_t sc_fast_workspace_bytes(long long n_frames) { return (size_t)n_frames * (sizeof(ScRec) + sizeof(int32_t)) + 64; }
 
@@ -532,17 +746,6 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     if (p.n_frames <= 0) return hipSuccess;
     const int wg = sc_fast_pick_wg(p);
     const size_t lds = sc_fast_lds_bytes(p.L, wg);
-    static bool attr_set[64] = {false}; // per device, once: the call is not free and sits on the launch path
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sc_fast<512>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sc_fast<256>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
     ScRec *rec = reinterpret_cast<ScRec *>(workspace);
     int32_t *slow_count = reinterpret_cast<int32_t *>(rec + p.n_frames);
     int32_t *slow_list = slow_count + 4;
@@ -550,22 +753,22 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     if (e != hipSuccess) return e;
     ScFastParams q;
     q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride;
-    const long long tile_n = (long long)wg * SP_C;
+    const long long tile_n = (long long)wg * 10;
     const long long stage = p.frame_len < tile_n ? p.frame_len : tile_n;
     q.n16 = (int)(stage / 2);
     q.n_lags = (int)p.n_lags; q.L = p.L; q.W = p.W;
     q.thr = p.threshold;
+    { const char *e = getenv("OFDM_SC_DEBUG"); q.debug = e ? atoi(e) : 0; }
     q.thr_lo = (float)(p.threshold * (1.0 - (double)SC_EPS));
     q.thr_hi = (float)(p.threshold * (1.0 + (double)SC_EPS));
     q.d_hat = p.d_hat; q.rec = rec; q.slow_list = slow_list; q.slow_count = slow_count;
-    // persistent over the frame list; workgroups per CU are LDS-bound (2 x 512, 4 x 256, 7 x 128 threads)
+    // persistent over the frame list; workgroups per CU: LDS-bound and capped at 16 waves per CU (128 VGPRs)
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
-    if (per_cu > 2048 / wg) per_cu = 2048 / wg;
+    if (per_cu > 768 / wg) per_cu = 768 / wg; // 149 VGPRs -> 3 waves per SIMD -> 12 waves per CU
     long long grid = (long long)num_cu * per_cu;
     if (grid > p.n_frames) grid = p.n_frames;
-    if (wg == 512) hipLaunchKernelGGL(k_sc_fast<512>, dim3((unsigned)grid), dim3(512), lds, st, q);
-    else if (wg == 256) hipLaunchKernelGGL(k_sc_fast<256>, dim3((unsigned)grid), dim3(256), lds, st, q);
-    else hipLaunchKernelGGL(k_sc_fast<128>, dim3((unsigned)grid), dim3(128), lds, st, q);
+    if (wg == 256) hipLaunchKernelGGL(k_sc_fast2<256>, dim3((unsigned)grid), dim3(256), lds, st, q);
+    else hipLaunchKernelGGL(k_sc_fast2<128>, dim3((unsigned)grid), dim3(128), lds, st, q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, rec, p.n_frames, p.L,
                        p.f_delta, p.metric);

@@ -465,3 +465,19 @@ def test_edge_cases(api, orc):
     pay = rng.integers(0, 256, (1, 9000), dtype=np.uint8)
     frames = host(ctx.encode_batch(torch.from_numpy(pay).to(ctx.device)))
     assert rel_err(frames[0], orc.encode(bytes(pay[0]), True, orc.QAM256, 4096)) <= TOL
+
+
+# ------------------------------------------------------------------ C++ host mirror (include/ofdm_host.hpp): lab3a / lab3b loop-back
+def test_cpp_host_loopback(ofdm):
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "ofdm_loopback")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tools", "ofdm_loopback.cpp"), "-L", os.path.join(root, "ofdm_amd"), "-lofdm_hip",
+                           "-Wl,-rpath," + os.path.join(root, "ofdm_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
+    for args in ([], ["--timing-error"], ["--guard", "--qam64", "--bytes", "560", "--timing-error"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (args, r.stdout, r.stderr)          # exit 0 <=> Analysis.num_errs == 0
+        assert "num_errs: 0" in r.stdout and "I met a traveller" in r.stdout

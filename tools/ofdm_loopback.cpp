@@ -1,0 +1,72 @@
+// ofdm_loopback -- the reference's loop-back examples (examples/lab3a.rs:11-46, lab3b.rs:12-38) on the GPU path:
+//   text -> encode -> channel(FIR + optional CFO + noise, seeded) -> decode -> Analysis + print.
+// The channel here is bench plumbing (src/channel.rs:26-74 re-stated with a seeded SplitMix64 instead of thread_rng);
+// encode / decode are the library.  Build: g++ -std=c++17 -I include tools/ofdm_loopback.cpp -L ofdm_amd -lofdm_hip
+#include "ofdm_host.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+using namespace ofdm;
+
+static const double CHANNEL[64] = {0, 0, 0, 0, 0, 0, 0, -0.0, -0.1912, 0.9316, 0.2821, -0.1990, 0.1630, -0.1017, 0.0544, -0.0261, 0.0090, 0.0, -0.0034};
+
+static uint64_t sm64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static double u01(uint64_t &s) { return (double)(sm64(s) >> 11) * (1.0 / 9007199254740992.0); }
+
+static std::vector<Complex64> channel(const std::vector<Complex64> &tx, double snr_db, bool timing_error, uint64_t seed, double *fd_used) {
+    std::vector<Complex64> y(tx.size() + 63, Complex64(0, 0));
+    for (size_t i = 0; i < tx.size(); ++i)
+        for (int k = 8; k <= 18; ++k) y[i + k] += tx[i] * CHANNEL[k]; // convolve(CHANNEL): taps 8..18 are the non-zero ones
+    uint64_t st = seed;
+    double fd = 0.0;
+    if (timing_error) {
+        fd = M_PI * (u01(st) / 80.0); // src/channel.rs:54
+        for (size_t i = 0; i < y.size(); ++i) y[i] *= std::exp(Complex64(0, fd * (double)(i + 1)));
+    }
+    if (fd_used) *fd_used = fd;
+    Complex64 mean(0, 0), var(0, 0);
+    for (auto &v : y) mean += v;
+    mean /= (double)y.size();
+    for (auto &v : y) var += (mean - v) * (mean - v); // complex pseudo-variance (src/signals/mod.rs:239-249)
+    var /= (double)y.size();
+    const Complex64 scale = std::sqrt(0.5 * var / std::pow(10.0, snr_db / 10.0));
+    for (auto &v : y) { const double re = u01(st) * 2 - 1, im = u01(st) * 2 - 1; v += scale * Complex64(re, im); }
+    return y;
+}
+
+int main(int argc, char **argv) {
+    const char *corpus = "I met a traveller from an antique land, Who said: Two vast and trunkless legs of stone Stand in the desert. ";
+    size_t num_bytes = 400;
+    bool guard_bands = false, timing_error = false;
+    ModulationScheme modulation = ModulationScheme::Qpsk;
+    for (int i = 1; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--timing-error")) timing_error = true;          // lab3b
+        else if (!std::strcmp(argv[i], "--guard")) guard_bands = true;
+        else if (!std::strcmp(argv[i], "--qam64")) modulation = ModulationScheme::Qam64;
+        else if (!std::strcmp(argv[i], "--bytes") && i + 1 < argc) num_bytes = (size_t)std::atol(argv[++i]);
+    }
+    try {
+        std::vector<uint8_t> source(num_bytes);
+        for (size_t i = 0; i < num_bytes; ++i) source[i] = (uint8_t)corpus[i % std::strlen(corpus)]; // create_transmission_text
+        auto tx = encode(source, guard_bands, modulation);                         // ofdm::encode!
+        double fd = 0;
+        auto rx = channel(tx, 30.0, timing_error, 2021, &fd);                      // ofdm::channel!(snr: 30.0[, timing_error])
+        auto received = decode(std::move(rx), guard_bands, modulation);            // ofdm::decode!
+        if (received.size() != source.size()) { std::printf("length mismatch: %zu vs %zu\n", received.size(), source.size()); return 2; }
+        Analysis a(source, received);
+        std::printf("Analysis { num_errs: %u, num_block_errs: %u, err_rate: %g }  samples: %zu  f_delta: %g\n", a.num_errs,
+                    a.num_block_errs, a.err_rate, tx.size(), fd);
+        std::printf("%.*s\n", (int)std::min<size_t>(received.size(), 100), (const char *)received.data());
+        return a.num_errs == 0 ? 0 : 1;
+    } catch (const std::exception &e) {
+        std::printf("error: %s\n", e.what());
+        return 3;
+    }
+}
