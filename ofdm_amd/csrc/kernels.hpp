@@ -85,7 +85,7 @@ size_t sc_lds_bytes(const ScParams &p);
 hipError_t run_sc(const ScParams &p, hipStream_t st);
 // fast path for one-tile frames with a short period (f32 filter + exact f64 decisions; kernels_sync.hip)
 bool sc_fast_ok(const ScParams &p);
-size_t sc_fast_workspace_bytes(long long n_frames);
+size_t sc_fast_workspace_bytes(long long n_frames, int W);
 hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st);
 hipError_t run_sc_min_cross(const long long *cross, int tiles_per_frame, long long n_frames, int32_t *d1, hipStream_t st);
 hipError_t run_freq_correction(const float2 *in, long long n_pairs, long long stride, long long right_offset, int L,

@@ -215,23 +215,18 @@ int sc_tile_lags() { return SC_CH; }
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_sc_fast: the fast Schmidl-Cox path for one-tile frames with a short period (W + L well below the 2560-sample
-// tile, i.e. N <= 256) and 16-byte aligned frame bases.  "Filter in f32, decide in f64":
-//   * persistent 512-thread workgroups (2 per CU) walk the frame list; a frame's raw fc32 samples arrive by
-//     direct-to-LDS loads (global_load_lds_dwordx4 from inline asm: no VGPR staging, not drained by barriers) into a
-//     double buffer, so frame k+1 is in flight while frame k is correlated (staging alone streams at 6.4 TB/s);
-//   * every product q[n] = conj(r[n]) r[n+L] and energy e[n] = |r[n]|^2 is formed ONCE, in f32; each thread owns 5
-//     consecutive samples and writes its exclusive local prefix sums to LDS; the scan over the thread totals is a
-//     DPP wavefront scan (row shifts / broadcasts) plus 8 wave totals;
-//   * a lag is four prefix differences:  P(d) = C_q[d+W] - C_q[d],  E(d) = C_e[d+W] - C_e[d],  R(d) = E(d+L)
-//     (5 | L and 5 | W, so all of a thread's lags share the same chunk bases);
+// Fast Schmidl-Cox path for one-tile frames with a short period (N <= 256) and 16-byte aligned frame bases:
+// "filter in f32, decide in f64".
+//   * every product q[n] = conj(r[n]) r[n+L] and energy e[n] = |r[n]|^2 is formed ONCE, in f32; each thread owns a run
+//     of consecutive samples and writes its exclusive local prefix sums to LDS; a DPP wavefront scan (row shifts /
+//     broadcasts) plus the wave totals give every chunk's base;
+//   * a lag is four prefix differences:  P(d) = C_q[d+W] - C_q[d],  E(d) = C_e[d+W] - C_e[d],  R(d) = E(d+L);
 //   * decisions are EXACT: the f32 metric (absolute error <= ~5e-6 x prefix-energy / window-energy) only filters.
 //     The first crossing is accepted from f32 when "M >= thr(1-EPS)" and "M >= thr(1+EPS)" first hold at the same lag;
-//     the peak is re-evaluated in f64 (wave 0, from the raw samples still in LDS; products of f32 are exact in f64) at
-//     every lag within 2 EPS of the f32 window maximum.  Lags whose error bound is not small (prefix energy > 20x
-//     window energy) are never trusted.  Frames the filter cannot settle (ambiguous crossing, > 4 peak candidates)
-//     go to a device-side list and are redone by the all-f64 kernel k_sc_tile.  Outputs equal the f64 oracle's.
-constexpr int SP_C = 5; // samples (and lags) per thread; the tile holds 5 * WG samples (WG = 128, 256 or 512 threads)
+//     the peak is re-evaluated in f64 (products of f32 are exact in f64) at every lag within 2 EPS of the f32 window
+//     maximum.  Lags whose error bound is not small (prefix energy > 20x window energy) are never trusted.  Frames the
+//     filter cannot settle (ambiguous crossing, > 4 peak candidates) go to a device-side list and are redone by the
+//     all-f64 kernel k_sc_tile.  Outputs equal the f64 oracle's.
 constexpr float SC_EPS = 1e-3f;         // relative guard band of the f32 filter around the threshold / the maximum
 constexpr float SC_UNSAFE_RATIO = 20.f; // prefix energy / window energy above which a lag is never trusted
 constexpr int SC_MAXCAND = 4;
@@ -287,7 +282,9 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char *)p);
 }
 
-struct ScRec { double pr, pi, num, den; }; // exact sums at the chosen lag (finish kernel turns them into CFO / metric)
+// what the filter kernel hands to the finish kernel: the first crossing d1 and the f32 metric of the nwin lags of
+// [d1, d1 + W] (in mwin; +inf marks a lag the filter does not trust, -1 a lag without energy)
+struct ScRec { int32_t state; int32_t d1; int32_t nwin; int32_t pad; }; // state: -1 no packet, -2 slow list, 1 window stored
 
 struct ScFastParams {
     const float2 *in;
@@ -299,203 +296,11 @@ struct ScFastParams {
     double thr;
     int32_t *d_hat;
     ScRec *rec;
+    float *mwin;    // [n_frames][wstride] f32 metric over the peak window
+    int wstride;
     int32_t *slow_list; // frames the filter could not settle
     int32_t *slow_count;
 };
-
-template <int SP_WG>
-__global__ __launch_bounds__(SP_WG, (SP_WG == 512 ? 4 : 2)) void k_sc_fast(ScFastParams p) {
-    constexpr int SP_N = SP_WG * SP_C, NW = SP_WG / 64;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int L = p.L, W = p.W, n = p.n_lags;
-    const int rspan = SP_N + L; // raw slab (entries past the staged samples are never used by a valid lag)
-    cf *raw0 = reinterpret_cast<cf *>(smem);
-    cf *raw1 = raw0 + rspan;
-    float2 *lq = reinterpret_cast<float2 *>(raw1 + rspan); // [SP_N] exclusive local prefix of q
-    float2 *bq = lq + SP_N;                                // [SP_WG] chunk bases
-    float *le = reinterpret_cast<float *>(bq + SP_WG);     // [SP_N] exclusive local prefix of e
-    float *be = le + SP_N;                                 // [SP_WG]
-    float *wtot = be + SP_WG;                              // [NW][4] wave totals (qr, qi, e, -)
-    int *sh = reinterpret_cast<int *>(wtot + 32);          // [2][8] per-parity: lo, hi, max bits, count, cand[4]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cL = L / SP_C, cW = W / SP_C;
-    const unsigned raw_lds[2] = {lds_addr(raw0), lds_addr(raw1)};
-    const int n0 = tid * SP_C;
-    const bool has_samples = n0 < 2 * p.n16; // threads past the staged samples contribute zeros
-    const bool live = n0 < n;                // this thread owns at least one searched lag
-
-    long long f = blockIdx.x;
-    const long long fstep = gridDim.x;
-    // stage(frame, buffer): 1-KiB pieces dealt round-robin to the 8 waves
-    auto stage = [&](long long fr, int bufi) {
-        const char *sbase = reinterpret_cast<const char *>(p.in + fr * p.frame_stride);
-        for (int piece = wave; piece * 64 < p.n16; piece += SP_WG / 64) {
-            const int i = piece * 64 + lane;
-            if (i < p.n16) glds16(sbase, (unsigned)i * 16u, raw_lds[bufi] + (unsigned)piece * 1024u);
-        }
-    };
-    if (f < p.n_frames) stage(f, 0);
-    if (tid < 16) sh[tid] = (tid & 7) < 2 ? INT_MAX : 0;
-    int cur = 0;
-
-    for (; f < p.n_frames; f += fstep, cur ^= 1) {
-        const cf *raw = cur ? raw1 : raw0;
-        int *S = sh + cur * 8;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
-        lds_barrier();                                   // ... and everyone else's; previous frame fully consumed
-        if (f + fstep < p.n_frames) stage(f + fstep, cur ^ 1);
-        if (tid < 8) sh[(cur ^ 1) * 8 + tid] = tid < 2 ? INT_MAX : 0; // reset the other parity's slots (idle since last frame)
-
-        // ---- phase 1 (f32): products once per sample, exclusive local prefixes to LDS, own copies in registers
-        float2 oq[SP_C];
-        float oe[SP_C];
-        float rqr = 0.f, rqi = 0.f, re = 0.f;
-        if (has_samples) {
-            cf a[SP_C], b[SP_C];
-#pragma unroll
-            for (int j = 0; j < SP_C; ++j) { a[j] = raw[n0 + j]; b[j] = raw[n0 + j + L]; }
-#pragma unroll
-            for (int j = 0; j < SP_C; ++j) {
-                oq[j] = make_float2(rqr, rqi);
-                oe[j] = re;
-                lq[n0 + j] = oq[j];
-                le[n0 + j] = re;
-                rqr += a[j].x * b[j].x + a[j].y * b[j].y;
-                rqi += a[j].x * b[j].y - a[j].y * b[j].x;
-                re += a[j].x * a[j].x + a[j].y * a[j].y;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < SP_C; ++j) { oq[j] = make_float2(0.f, 0.f); oe[j] = 0.f; }
-        }
-        const float iqr = wave_scan_f(rqr), iqi = wave_scan_f(rqi), ie = wave_scan_f(re);
-        if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
-        lds_barrier();
-        // exclusive prefix of the 8 wave totals: lanes 0..7 hold one total each, 3 DPP steps, broadcast by readlane
-        float wq = lane < NW ? wtot[lane * 4 + 0] : 0.f, wi = lane < NW ? wtot[lane * 4 + 1] : 0.f,
-              we = lane < NW ? wtot[lane * 4 + 2] : 0.f;
-        float sq = wq, si = wi, se = we;
-        sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
-        sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
-        sq += dpp_s<0x114, 0xF>(sq); si += dpp_s<0x114, 0xF>(si); se += dpp_s<0x114, 0xF>(se);
-        const float mybqr = (iqr - rqr) + (readlane_f(sq, wave) - readlane_f(wq, wave));
-        const float mybqi = (iqi - rqi) + (readlane_f(si, wave) - readlane_f(wi, wave));
-        const float mybe = (ie - re) + (readlane_f(se, wave) - readlane_f(we, wave));
-        bq[tid] = make_float2(mybqr, mybqi);
-        be[tid] = mybe;
-        lds_barrier();
-
-        // ---- phase 2A (f32): metric at this thread's 5 lags; threshold-crossing candidates
-        float mr[SP_C];      // f32 metric, -1 where the lag is not searched / has no energy
-        unsigned force = 0u; // lags whose f32 error bound is too large to trust
-#pragma unroll
-        for (int j = 0; j < SP_C; ++j) mr[j] = -1.f;
-        if (live) { // implies tid + cW + cL < SP_WG
-            const float2 b1 = bq[tid + cW];
-            const float dBqr = b1.x - mybqr, dBqi = b1.y - mybqi;
-            const float etop = be[tid + cW + cL];
-            const float dBe = be[tid + cW] - mybe, dBr = etop - be[tid + cL];
-            float2 q1[SP_C];
-            float e1[SP_C], e2[SP_C], e3[SP_C];
-#pragma unroll
-            for (int j = 0; j < SP_C; ++j) {
-                q1[j] = lq[n0 + j + W];
-                e1[j] = le[n0 + j + W];
-                e2[j] = le[n0 + j + W + L];
-                e3[j] = le[n0 + j + L];
-            }
-            int lo = INT_MAX, hi = INT_MAX;
-#pragma unroll
-            for (int j = SP_C - 1; j >= 0; --j) {
-                const float pr = (q1[j].x - oq[j].x) + dBqr, pi = (q1[j].y - oq[j].y) + dBqi;
-                const float E = (e1[j] - oe[j]) + dBe, R = (e2[j] - e3[j]) + dBr;
-                const float den = E * R;
-                const bool ok = (n0 + j < n) && den > 0.f;
-                const float m = (pr * pr + pi * pi) * __builtin_amdgcn_rcpf(den);
-                mr[j] = ok ? m : -1.f;
-                const bool unsafe = ok && etop > SC_UNSAFE_RATIO * fminf(E, R);
-                if (unsafe) force |= 1u << j;
-                if (ok && (unsafe || m >= p.thr_lo)) lo = n0 + j;
-                if (ok && !unsafe && m >= p.thr_hi) hi = n0 + j;
-            }
-            if (lo != INT_MAX) atomicMin(&S[0], lo);
-            if (hi != INT_MAX) atomicMin(&S[1], hi);
-        }
-        lds_barrier();
-        const int c_lo = S[0], c_hi = S[1];
-        if (c_lo == INT_MAX) { // nothing reaches the threshold (exactly): no packet
-            if (tid == 0) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, 1.0}; }
-            continue;
-        }
-        if (c_lo != c_hi) { // the f32 filter cannot place the first crossing: redo this frame in f64
-            if (tid == 0) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, -1.0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; }
-            continue;
-        }
-        const int d1 = c_lo;
-        // ---- peak candidates: lags of [d1, d1 + W] within 2 EPS of the f32 window maximum, or untrusted
-        const bool inwin = live && n0 + SP_C > d1 && n0 <= d1 + W;
-        unsigned wmask = 0u;
-        if (inwin) {
-            float mloc = 0.f;
-#pragma unroll
-            for (int j = 0; j < SP_C; ++j) {
-                const int d = n0 + j;
-                if (d >= d1 && d <= d1 + W && mr[j] >= 0.f) {
-                    wmask |= 1u << j;
-                    if (!((force >> j) & 1u)) mloc = fmaxf(mloc, mr[j]);
-                }
-            }
-            if (mloc > 0.f) atomicMax(reinterpret_cast<unsigned *>(&S[2]), __float_as_uint(mloc));
-        }
-        lds_barrier();
-        if (inwin) {
-            const float mcut = __uint_as_float((unsigned)S[2]) * (1.f - 2.f * SC_EPS);
-#pragma unroll
-            for (int j = 0; j < SP_C; ++j) {
-                if (((wmask >> j) & 1u) && (((force >> j) & 1u) || mr[j] >= mcut)) {
-                    const int slot = atomicAdd(&S[3], 1);
-                    if (slot < SC_MAXCAND) S[4 + slot] = n0 + j;
-                }
-            }
-        }
-        lds_barrier();
-        // ---- exact decision by wave 0 only (the other waves move on and wait at the next frame's barrier)
-        if (wave == 0) {
-            const int cnt = S[3];
-            if (cnt > SC_MAXCAND || cnt <= 0) {
-                if (lane == 0) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, -1.0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; }
-            } else {
-                Cand best = Cand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
-                for (int i = 0; i < cnt; ++i) {
-                    const int d = S[4 + i];
-                    double xr = 0, xi = 0, xe = 0, xq = 0;
-                    for (int m = lane; m < W; m += 64) {
-                        const cf a = raw[d + m], b = raw[d + m + L];
-                        const double ar = a.x, ai = a.y, br = b.x, bi = b.y;
-                        xr += ar * br + ai * bi;
-                        xi += ar * bi - ai * br;
-                        xe += ar * ar + ai * ai;
-                        xq += br * br + bi * bi;
-                    }
-                    xr = readlane_d(wave_scan(xr), 63); xi = readlane_d(wave_scan(xi), 63);
-                    xe = readlane_d(wave_scan(xe), 63); xq = readlane_d(wave_scan(xq), 63);
-                    const double xn = xr * xr + xi * xi, xd = xe * xq;
-                    // first maximum wins: strictly greater, or equal at a lower lag (candidates arrive unordered)
-                    if (xd > 0.0) {
-                        const double lhs = xn * best.den, rhs = best.num * xd;
-                        if (lhs > rhs || (lhs == rhs && d < best.lag)) best = Cand{xn, xd, xr, xi, d};
-                    }
-                }
-                if (lane == 0) {
-                    if (best.lag == INT_MAX) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, 1.0}; }
-                    else { p.d_hat[f] = best.lag; p.rec[f] = ScRec{best.pr, best.pi, best.num, best.den}; }
-                }
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_sc_fast2: second-generation fast path (same "filter in f32, decide in f64" contract as k_sc_fast), shaped by
@@ -545,6 +350,7 @@ __global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
         int *S = sh + cur * 8;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
         lds_barrier();                                   // B0: ... and everyone else's
+        const bool more = f + fstep < p.n_frames;
         if (tid < 8) sh[(cur ^ 1) * 8 + tid] = tid < 2 ? INT_MAX : 0;
         // ---- raw tile -> registers (16-byte LDS reads)
         cf a[C], b[C];
@@ -591,13 +397,13 @@ __global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
         bq[tid] = make_float2(mybqr, mybqi);
         be[tid] = mybe;
         lds_barrier(); // B3
-        if (p.debug == 2) { if (more_dbg(p, f, fstep)) stage(f + fstep); continue; }
+        if (p.debug == 2) { if (more && p.debug != 1) stage(f + fstep); continue; }
 
-        // ---- phase 2A (f32): metric at this thread's 10 lags; threshold-crossing candidates
-        float mr[C];
-        unsigned force = 0u;
+        // ---- phase 2A (f32): metric at this thread's 10 lags, two lags per packed op
+        float2 mp[C / 2];     // f32 metric of lags (2i, 2i+1); -1 where the lag is not searched / has no energy
+        bool unsafe_t = false; // this thread's lags are not trusted (prefix energy >> window energy): decided exactly
 #pragma unroll
-        for (int j = 0; j < C; ++j) mr[j] = -1.f;
+        for (int i = 0; i < C / 2; ++i) mp[i] = make_float2(-1.f, -1.f);
         if (live) {
             const float2 b1 = bq[tid + cW];
             const float dBqr = b1.x - mybqr, dBqi = b1.y - mybqi;
@@ -606,119 +412,138 @@ __global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
             const float4 *pq = reinterpret_cast<const float4 *>(lq + n0 + W), *pq0 = reinterpret_cast<const float4 *>(lq + n0);
             const float2 *p1 = reinterpret_cast<const float2 *>(le + n0 + W), *p2 = reinterpret_cast<const float2 *>(le + n0 + W + L),
                          *p3 = reinterpret_cast<const float2 *>(le + n0 + L), *p0 = reinterpret_cast<const float2 *>(le + n0);
-            int lo = INT_MAX, hi = INT_MAX;
+            float emin = 3.0e38f, mmax = -1.f;
 #pragma unroll
-            for (int i = C / 2 - 1; i >= 0; --i) {
+            for (int i = 0; i < C / 2; ++i) {
                 const float4 q4 = pq[i], o4 = pq0[i];
                 const float2 x1 = p1[i], x2 = p2[i], x3 = p3[i], x0 = p0[i];
-#pragma unroll
-                for (int h = 1; h >= 0; --h) {
-                    const int j = 2 * i + h;
-                    const float q1x = h ? q4.z : q4.x, q1y = h ? q4.w : q4.y;
-                    const float e1 = h ? x1.y : x1.x, e2 = h ? x2.y : x2.x, e3 = h ? x3.y : x3.x;
-                    const float oqx = h ? o4.z : o4.x, oqy = h ? o4.w : o4.y, oe0 = h ? x0.y : x0.x;
-                    const float pr = (q1x - oqx) + dBqr, pi = (q1y - oqy) + dBqi;
-                    const float E = (e1 - oe0) + dBe, R = (e2 - e3) + dBr;
-                    const float den = E * R;
-                    const bool ok = (n0 + j < n) && den > 0.f;
-                    const float m = (pr * pr + pi * pi) * __builtin_amdgcn_rcpf(den);
-                    mr[j] = ok ? m : -1.f;
-                    const bool unsafe = ok && etop > SC_UNSAFE_RATIO * fminf(E, R);
-                    if (unsafe) force |= 1u << j;
-                    if (ok && (unsafe || m >= p.thr_lo)) lo = n0 + j;
-                    if (ok && !unsafe && m >= p.thr_hi) hi = n0 + j;
-                }
+                const float2 E = make_float2((x1.x - x0.x) + dBe, (x1.y - x0.y) + dBe);
+                const float2 R = make_float2((x2.x - x3.x) + dBr, (x2.y - x3.y) + dBr);
+                const float2 den = make_float2(E.x * R.x, E.y * R.y);
+                const float ar = (q4.x - o4.x) + dBqr, ai = (q4.y - o4.y) + dBqi, br = (q4.z - o4.z) + dBqr, bi = (q4.w - o4.w) + dBqi;
+                const float2 num = make_float2(ar * ar + ai * ai, br * br + bi * bi);
+                const bool ok0 = den.x > 0.f && n0 + 2 * i < n, ok1 = den.y > 0.f && n0 + 2 * i + 1 < n;
+                mp[i].x = ok0 ? num.x * __builtin_amdgcn_rcpf(den.x) : -1.f;
+                mp[i].y = ok1 ? num.y * __builtin_amdgcn_rcpf(den.y) : -1.f;
+                emin = fminf(emin, fminf(ok0 ? fminf(E.x, R.x) : 3.0e38f, ok1 ? fminf(E.y, R.y) : 3.0e38f));
+                mmax = fmaxf(mmax, fmaxf(mp[i].x, mp[i].y));
             }
-            if (lo != INT_MAX) atomicMin(&S[0], lo);
-            if (hi != INT_MAX) atomicMin(&S[1], hi);
+            unsafe_t = etop > SC_UNSAFE_RATIO * emin; // emin stays huge when no lag has energy
+            if (unsafe_t || mmax >= p.thr_lo) {        // only threads near the packet scan their lags for the crossing
+                int lo = INT_MAX, hi = INT_MAX;
+#pragma unroll
+                for (int j = C - 1; j >= 0; --j) {
+                    const float m = (j & 1) ? mp[j >> 1].y : mp[j >> 1].x;
+                    if (m >= 0.f && (unsafe_t || m >= p.thr_lo)) lo = n0 + j;
+                    if (m >= 0.f && !unsafe_t && m >= p.thr_hi) hi = n0 + j;
+                }
+                if (lo != INT_MAX) atomicMin(&S[0], lo);
+                if (hi != INT_MAX) atomicMin(&S[1], hi);
+            }
         }
         lds_barrier(); // B4: prefixes are dead from here on
         const int c_lo = S[0], c_hi = S[1];
-        const bool more = f + fstep < p.n_frames;
-        if (more && wave != 0 && p.debug != 1) stage(f + fstep); // wave 0 stages after its exact phase (its global loads share the VM queue)
+        // single raw tile: 3 workgroups per CU (more independent waves) measured faster than a double buffer with 2
+        if (more && p.debug != 1) stage(f + fstep);
+        if (p.debug == 3) continue;
         if (c_lo == INT_MAX || c_lo != c_hi) {
             if (tid == 0) {
                 p.d_hat[f] = -1;
-                if (c_lo == INT_MAX) p.rec[f] = ScRec{0.0, 0.0, 0.0, 1.0};         // nothing reaches the threshold: no packet
-                else { p.rec[f] = ScRec{0.0, 0.0, 0.0, -1.0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; } // ambiguous: redo in f64
+                if (c_lo == INT_MAX) p.rec[f] = ScRec{-1, 0, 0, 0}; // nothing reaches the threshold: no packet
+                else { p.rec[f] = ScRec{-2, 0, 0, 0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; } // ambiguous crossing: redo in f64
             }
-            if (more && wave == 0 && p.debug != 1) stage(f + fstep);
             continue;
         }
         const int d1 = c_lo;
-        // ---- peak candidates: lags of [d1, d1 + W] within 2 EPS of the f32 window maximum, or untrusted
-        const bool inwin = live && n0 + C > d1 && n0 <= d1 + W;
-        unsigned wmask = 0u;
-        if (inwin) {
-            float mloc = 0.f;
+        // ---- hand the peak window to the finish kernel: f32 metric of every lag of [d1, d1 + W] (exact compare there)
+        if (live && n0 + C > d1 && n0 <= d1 + W) {
+            float *mw = p.mwin + f * p.wstride;
 #pragma unroll
             for (int j = 0; j < C; ++j) {
                 const int d = n0 + j;
-                if (d >= d1 && d <= d1 + W && mr[j] >= 0.f) {
-                    wmask |= 1u << j;
-                    if (!((force >> j) & 1u)) mloc = fmaxf(mloc, mr[j]);
-                }
-            }
-            if (mloc > 0.f) atomicMax(reinterpret_cast<unsigned *>(&S[2]), __float_as_uint(mloc));
-        }
-        lds_barrier(); // B5
-        if (inwin) {
-            const float mcut = __uint_as_float((unsigned)S[2]) * (1.f - 2.f * SC_EPS);
-#pragma unroll
-            for (int j = 0; j < C; ++j) {
-                if (((wmask >> j) & 1u) && (((force >> j) & 1u) || mr[j] >= mcut)) {
-                    const int slot = atomicAdd(&S[3], 1);
-                    if (slot < SC_MAXCAND) S[4 + slot] = n0 + j;
-                }
+                const float m = (j & 1) ? mp[j >> 1].y : mp[j >> 1].x;
+                if (d >= d1 && d <= d1 + W && d < n) mw[d - d1] = (unsafe_t && m >= 0.f) ? __builtin_inff() : m;
             }
         }
-        lds_barrier(); // B6
-        // ---- exact decision by wave 0 only, samples re-read from global memory (L2)
-        if (wave == 0) {
-            const int cnt = S[3];
-            if (cnt > SC_MAXCAND || cnt <= 0) {
-                if (lane == 0) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, -1.0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; }
-            } else {
-                const cf *src = p.in + f * p.frame_stride;
-                Cand best = Cand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
-                for (int i = 0; i < cnt; ++i) {
-                    const int d = S[4 + i];
-                    double xr = 0, xi = 0, xe = 0, xq = 0;
-                    for (int m = lane; m < W; m += 64) {
-                        const cf sa = src[d + m], sb = src[d + m + L];
-                        const double ar = sa.x, ai = sa.y, br = sb.x, bi = sb.y;
-                        xr += ar * br + ai * bi;
-                        xi += ar * bi - ai * br;
-                        xe += ar * ar + ai * ai;
-                        xq += br * br + bi * bi;
-                    }
-                    xr = readlane_d(wave_scan(xr), 63); xi = readlane_d(wave_scan(xi), 63);
-                    xe = readlane_d(wave_scan(xe), 63); xq = readlane_d(wave_scan(xq), 63);
-                    const double xn = xr * xr + xi * xi, xd = xe * xq;
-                    if (xd > 0.0) { // first maximum wins: strictly greater, or equal at a lower lag (candidates arrive unordered)
-                        const double lhs = xn * best.den, rhs = best.num * xd;
-                        if (lhs > rhs || (lhs == rhs && d < best.lag)) best = Cand{xn, xd, xr, xi, d};
-                    }
-                }
-                if (lane == 0) {
-                    if (best.lag == INT_MAX) { p.d_hat[f] = -1; p.rec[f] = ScRec{0.0, 0.0, 0.0, 1.0}; }
-                    else { p.d_hat[f] = best.lag; p.rec[f] = ScRec{best.pr, best.pi, best.num, best.den}; }
-                }
-            }
-            if (more && p.debug != 1) stage(f + fstep);
+        if (tid == 0) {
+            const int nw = n - d1 < W + 1 ? n - d1 : W + 1;
+            p.rec[f] = ScRec{1, d1, nw, 0};
         }
     }
 }
 
-// CFO and metric from the exact sums (one thread per frame; slow frames are finished by k_sc_tile instead)
-__global__ __launch_bounds__(256) void k_sc_finish(const ScRec *rec, long long n_frames, int L, double *f_delta, float *metric) {
-    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+// Exact decision for the frames the filter settled: one wavefront per frame.  It takes the f32 window maximum, keeps the
+// lags within 2 EPS of it (plus the untrusted ones), re-evaluates those (<= 4) lags in f64 from global memory
+// (2 x W samples each, coalesced), keeps the first maximum, and writes timing, CFO and metric.  More than 4 candidates
+// (flat or untrusted windows) go to the slow list, which k_sc_tile redoes entirely in f64 afterwards.
+__global__ __launch_bounds__(256) void k_sc_finish(const ScRec *rec, const float *mwin, int wstride, const cf *in, long long n_frames,
+                                                   long long frame_stride, int L, int W, int32_t *d_hat, double *f_delta,
+                                                   float *metric, int32_t *slow_list, int32_t *slow_count) {
+    const int lane = threadIdx.x & 63;
+    const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= n_frames) return;
     const ScRec r = rec[f];
-    if (r.den < 0.0) return; // deferred to the exact kernel
-    const bool found = r.num > 0.0;
-    if (f_delta) f_delta[f] = found ? atan2(r.pi, r.pr) / (double)L : 0.0;
-    if (metric) metric[f] = found ? (float)(r.num / r.den) : 0.f;
+    if (r.state == -2) return; // already on the slow list
+    if (r.state != 1 || r.nwin <= 0) {
+        if (lane == 0) { d_hat[f] = -1; if (f_delta) f_delta[f] = 0.0; if (metric) metric[f] = 0.f; }
+        return;
+    }
+    const float *mw = mwin + f * wstride;
+    const int chunks = (r.nwin + 63) >> 6; // wave-uniform
+    float mmax = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        const int i = c * 64 + lane;
+        const float m = i < r.nwin ? mw[i] : -1.f;
+        if (m < 3.0e38f) mmax = fmaxf(mmax, m); // untrusted lags (+inf) do not define the maximum
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, s, 64));
+    const float mcut = mmax * (1.f - 2.f * SC_EPS);
+    int cand[SC_MAXCAND];
+    int cnt = 0;
+    for (int c = 0; c < chunks; ++c) {
+        const int i = c * 64 + lane;
+        const float m = i < r.nwin ? mw[i] : -1.f;
+        unsigned long long mask = __ballot(m >= 0.f && (m >= mcut || m > 3.0e38f));
+        while (mask) { // wave-uniform scalar loop over the set bits
+            const int bit = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            if (cnt < SC_MAXCAND) cand[cnt] = r.d1 + c * 64 + bit;
+            ++cnt;
+        }
+    }
+    if (cnt == 0 || cnt > SC_MAXCAND) {
+        if (lane == 0) { d_hat[f] = -1; if (cnt) slow_list[atomicAdd(slow_count, 1)] = (int32_t)f; else { if (f_delta) f_delta[f] = 0.0; if (metric) metric[f] = 0.f; } }
+        return;
+    }
+    const cf *src = in + f * frame_stride;
+    Cand best = Cand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
+#pragma unroll
+    for (int i = 0; i < SC_MAXCAND; ++i) {
+        if (i >= cnt) break;
+        const int d = cand[i];
+        double xr = 0, xi = 0, xe = 0, xq = 0;
+        for (int m = lane; m < W; m += 64) {
+            const cf sa = src[d + m], sb = src[d + m + L];
+            const double ar = sa.x, ai = sa.y, br = sb.x, bi = sb.y;
+            xr += ar * br + ai * bi;
+            xi += ar * bi - ai * br;
+            xe += ar * ar + ai * ai;
+            xq += br * br + bi * bi;
+        }
+        xr = readlane_d(wave_scan(xr), 63); xi = readlane_d(wave_scan(xi), 63);
+        xe = readlane_d(wave_scan(xe), 63); xq = readlane_d(wave_scan(xq), 63);
+        const double xn = xr * xr + xi * xi, xd = xe * xq;
+        if (xd > 0.0) { // candidates arrive in increasing lag order: strictly greater replaces (first maximum wins)
+            if (xn * best.den > best.num * xd) best = Cand{xn, xd, xr, xi, d};
+        }
+    }
+    if (lane == 0) {
+        const bool found = best.lag != INT_MAX;
+        d_hat[f] = found ? best.lag : -1;
+        if (f_delta) f_delta[f] = found ? atan2(best.pi, best.pr) / (double)L : 0.0;
+        if (metric) metric[f] = found ? (float)(best.num / best.den) : 0.f;
+    }
 }
 
 static size_t sc_fast_lds_bytes(int L, int wg) { // k_sc_fast2: raw tile (aliased by the q prefixes) + e prefixes + bases
@@ -737,9 +562,12 @@ bool sc_fast_ok(const ScParams &p) {
     // one tile per frame, 10 | L, 16-byte aligned even-length frames
     const int wg = sc_fast_pick_wg(p);
     return p.mode == 0 && wg != 0 && p.L % 10 == 0 && p.W % 10 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 &&
-           (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L, wg) <= 40 * 1024;
+           (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L, wg) <= 64 * 1024;
 }
-size_t sc_fast_workspace_bytes(long long n_frames) { return (size_t)n_frames * (sizeof(ScRec) + sizeof(int32_t)) + 64; }
+static int sc_wstride(int W) { return ((W + 1 + 63) / 64) * 64; }
+size_t sc_fast_workspace_bytes(long long n_frames, int W) {
+    return (size_t)n_frames * (sizeof(ScRec) + sizeof(int32_t) + sizeof(float) * (size_t)sc_wstride(W)) + 64;
+}
 
 // p.mode == 0, p.tiles_per_frame == 1.  workspace: sc_fast_workspace_bytes(n_frames) bytes of device memory.
 hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st) {
@@ -747,7 +575,9 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     const int wg = sc_fast_pick_wg(p);
     const size_t lds = sc_fast_lds_bytes(p.L, wg);
     ScRec *rec = reinterpret_cast<ScRec *>(workspace);
-    int32_t *slow_count = reinterpret_cast<int32_t *>(rec + p.n_frames);
+    const int wstride = sc_wstride(p.W);
+    float *mwin = reinterpret_cast<float *>(rec + p.n_frames);
+    int32_t *slow_count = reinterpret_cast<int32_t *>(mwin + (size_t)p.n_frames * wstride);
     int32_t *slow_list = slow_count + 4;
     hipError_t e = hipMemsetAsync(slow_count, 0, 16, st);
     if (e != hipSuccess) return e;
@@ -761,17 +591,17 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     { const char *e = getenv("OFDM_SC_DEBUG"); q.debug = e ? atoi(e) : 0; }
     q.thr_lo = (float)(p.threshold * (1.0 - (double)SC_EPS));
     q.thr_hi = (float)(p.threshold * (1.0 + (double)SC_EPS));
-    q.d_hat = p.d_hat; q.rec = rec; q.slow_list = slow_list; q.slow_count = slow_count;
+    q.d_hat = p.d_hat; q.rec = rec; q.mwin = mwin; q.wstride = wstride; q.slow_list = slow_list; q.slow_count = slow_count;
     // persistent over the frame list; workgroups per CU: LDS-bound and capped at 16 waves per CU (128 VGPRs)
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
-    if (per_cu > 768 / wg) per_cu = 768 / wg; // 149 VGPRs -> 3 waves per SIMD -> 12 waves per CU
+    if (per_cu > 768 / wg) per_cu = 768 / wg; // ~150 VGPRs -> 3 waves per SIMD -> 12 waves per CU (4 with spills measured slower)
     long long grid = (long long)num_cu * per_cu;
     if (grid > p.n_frames) grid = p.n_frames;
     if (wg == 256) hipLaunchKernelGGL(k_sc_fast2<256>, dim3((unsigned)grid), dim3(256), lds, st, q);
     else hipLaunchKernelGGL(k_sc_fast2<128>, dim3((unsigned)grid), dim3(128), lds, st, q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, rec, p.n_frames, p.L,
-                       p.f_delta, p.metric);
+    hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((p.n_frames + 3) / 4)), dim3(256), 0, st, rec, mwin, wstride, p.in, p.n_frames,
+                       p.frame_stride, p.L, p.W, p.d_hat, p.f_delta, p.metric, slow_list, slow_count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // frames the filter could not settle: all-f64 kernel over the device-side list (usually empty)
     ScParams s = p;

@@ -412,7 +412,7 @@ static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame
     p.tiles_per_frame = 1; p.mode = 0;
     if (sc_fast_ok(p)) {
         void *wsp;
-        int rc = ws_get(c, 6, sc_fast_workspace_bytes(n_frames), &wsp);
+        int rc = ws_get(c, 6, sc_fast_workspace_bytes(n_frames, p.W), &wsp);
         if (rc) return rc;
         HIP_TRY(c, run_sc_fast(p, wsp, c->num_cu, c->stream));
         return OFDM_OK;
