@@ -481,3 +481,19 @@ def test_cpp_host_loopback(ofdm):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, (args, r.stdout, r.stderr)          # exit 0 <=> Analysis.num_errs == 0
         assert "num_errs: 0" in r.stdout and "I met a traveller" in r.stdout
+    # fc32 file wire format + capture slicing (examples/lab3c.rs:15-54, src/utils.rs:228-254)
+    import tempfile
+    import numpy as np
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "tx.fc32")
+        r = subprocess.run([exe, "--transmit", path], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and os.path.getsize(path) == 2880 * 8          # 400 B QPSK frame, 8 B per sample
+        tx = np.fromfile(path, dtype=np.float32).reshape(-1, 2)
+        assert abs(max(tx[:, 0].max(), tx[:, 1].max()) - 1.0) < 1e-6            # normalised frame (transmitter.rs:183-194)
+        cap = np.concatenate([np.zeros((1234, 2), np.float32), tx, np.zeros((777, 2), np.float32)])
+        cap += np.random.default_rng(0).standard_normal(cap.shape).astype(np.float32) * 1e-3
+        cpath = os.path.join(td, "rx.fc32")
+        cap.tofile(cpath)
+        for extra in ([], ["--start", "1000", "--stop", "4700"]):
+            r = subprocess.run([exe, "--receive", cpath] + extra, capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0 and "received 400 bytes" in r.stdout, (extra, r.stdout)

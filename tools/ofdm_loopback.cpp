@@ -41,21 +41,62 @@ static std::vector<Complex64> channel(const std::vector<Complex64> &tx, double s
     return y;
 }
 
+// fc32 wire format (src/utils.rs:228-254): native-endian f32 pairs (re, im), what UHD's tx_samples_from_file /
+// rx_samples_to_file --type float read and write (data/transmit.sh, data/receive.sh).
+static bool write_fc32(const char *path, const std::vector<Complex64> &x) {
+    FILE *fh = std::fopen(path, "wb");
+    if (!fh) return false;
+    for (auto &v : x) { const float p[2] = {(float)v.real(), (float)v.imag()}; std::fwrite(p, sizeof(float), 2, fh); }
+    std::fclose(fh);
+    return true;
+}
+static bool read_fc32(const char *path, std::vector<Complex64> &x, long start, long stop) {
+    FILE *fh = std::fopen(path, "rb");
+    if (!fh) return false;
+    float p[2];
+    long i = 0;
+    while (std::fread(p, sizeof(float), 2, fh) == 2) { // chunks_exact(8): a trailing partial sample is dropped
+        if (i >= start && (stop < 0 || i < stop)) x.emplace_back(p[0], p[1]);
+        ++i;
+    }
+    std::fclose(fh);
+    return true;
+}
+
 int main(int argc, char **argv) {
     const char *corpus = "I met a traveller from an antique land, Who said: Two vast and trunkless legs of stone Stand in the desert. ";
     size_t num_bytes = 400;
     bool guard_bands = false, timing_error = false;
     ModulationScheme modulation = ModulationScheme::Qpsk;
+    const char *tx_file = nullptr, *rx_file = nullptr; // examples/lab3c.rs: --transmit f / --receive f [--start a --stop b]
+    long start = 0, stop = -1;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--timing-error")) timing_error = true;          // lab3b
         else if (!std::strcmp(argv[i], "--guard")) guard_bands = true;
         else if (!std::strcmp(argv[i], "--qam64")) modulation = ModulationScheme::Qam64;
         else if (!std::strcmp(argv[i], "--bytes") && i + 1 < argc) num_bytes = (size_t)std::atol(argv[++i]);
+        else if (!std::strcmp(argv[i], "--transmit") && i + 1 < argc) tx_file = argv[++i];
+        else if (!std::strcmp(argv[i], "--receive") && i + 1 < argc) rx_file = argv[++i];
+        else if (!std::strcmp(argv[i], "--start") && i + 1 < argc) start = std::atol(argv[++i]);
+        else if (!std::strcmp(argv[i], "--stop") && i + 1 < argc) stop = std::atol(argv[++i]);
     }
     try {
         std::vector<uint8_t> source(num_bytes);
         for (size_t i = 0; i < num_bytes; ++i) source[i] = (uint8_t)corpus[i % std::strlen(corpus)]; // create_transmission_text
+        if (rx_file) { // decode a stored capture (or a slice of it)
+            std::vector<Complex64> cap;
+            if (!read_fc32(rx_file, cap, start, stop)) { std::printf("cannot read %s\n", rx_file); return 4; }
+            auto received = decode(std::move(cap), guard_bands, modulation);
+            std::printf("received %zu bytes\n%.*s\n", received.size(), (int)std::min<size_t>(received.size(), 100), (const char *)received.data());
+            if (received.size() != source.size()) return 2;
+            return Analysis(source, received).num_errs == 0 ? 0 : 1;
+        }
         auto tx = encode(source, guard_bands, modulation);                         // ofdm::encode!
+        if (tx_file) { // write the frame for tx_samples_from_file
+            if (!write_fc32(tx_file, tx)) { std::printf("cannot write %s\n", tx_file); return 4; }
+            std::printf("wrote %zu samples (%zu bytes) to %s\n", tx.size(), tx.size() * 8, tx_file);
+            return 0;
+        }
         double fd = 0;
         auto rx = channel(tx, 30.0, timing_error, 2021, &fd);                      // ofdm::channel!(snr: 30.0[, timing_error])
         auto received = decode(std::move(rx), guard_bands, modulation);            // ofdm::decode!
