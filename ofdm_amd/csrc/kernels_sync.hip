@@ -300,6 +300,7 @@ struct ScFastParams {
     int wstride;
     int32_t *slow_list; // frames the filter could not settle
     int32_t *slow_count;
+    struct ScExact *exact; // k_sc_cf: exact sums at the chosen lag, per frame
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -317,10 +318,12 @@ __global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
     constexpr int C = 10, TN = WG * C, NW = WG / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     const int L = p.L, W = p.W, n = p.n_lags;
-    cf *raw = reinterpret_cast<cf *>(smem);                 // [TN + L] raw tile ...
-    float2 *lq = reinterpret_cast<float2 *>(smem);          // ... later overwritten by [TN] exclusive local prefix of q
-    float *le = reinterpret_cast<float *>(raw + TN + L);    // [TN] exclusive local prefix of e
-    float2 *bq = reinterpret_cast<float2 *>(le + TN);       // [WG] chunk bases
+    // arrays are sized to the staged samples (ns = 2 * n16 <= TN), not to the tile: a 2176-sample frame needs 47 KB
+    const int ns = (2 * p.n16 + C - 1) / C * C; // whole 10-sample chunks
+    cf *raw = reinterpret_cast<cf *>(smem);                 // [ns + L] raw samples (entries past ns are never used by a valid lag)
+    float2 *lq = reinterpret_cast<float2 *>(raw + ns + L);  // [ns] exclusive local prefix of q
+    float *le = reinterpret_cast<float *>(lq + ns);         // [ns] exclusive local prefix of e
+    float2 *bq = reinterpret_cast<float2 *>(le + ns);       // [WG] chunk bases
     float *be = reinterpret_cast<float *>(bq + WG);         // [WG]
     float *wtot = be + WG;                                  // [NW][4] wave totals
     int *sh = reinterpret_cast<int *>(wtot + 4 * NW);       // [2][8] per-parity: lo, hi, max bits, count, cand[4]
@@ -352,21 +355,17 @@ __global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
         lds_barrier();                                   // B0: ... and everyone else's
         const bool more = f + fstep < p.n_frames;
         if (tid < 8) sh[(cur ^ 1) * 8 + tid] = tid < 2 ? INT_MAX : 0;
-        // ---- raw tile -> registers (16-byte LDS reads)
-        cf a[C], b[C];
+        // ---- phase 1 (f32): products once per sample (16-byte LDS reads), exclusive local prefixes to LDS
+        float rqr = 0.f, rqi = 0.f, re = 0.f;
         if (has_samples) {
             const float4 *pa = reinterpret_cast<const float4 *>(raw + n0), *pb = reinterpret_cast<const float4 *>(raw + n0 + L);
+            cf a[C], b[C];
 #pragma unroll
             for (int i = 0; i < C / 2; ++i) {
                 const float4 x = pa[i], y = pb[i];
                 a[2 * i] = make_float2(x.x, x.y); a[2 * i + 1] = make_float2(x.z, x.w);
                 b[2 * i] = make_float2(y.x, y.y); b[2 * i + 1] = make_float2(y.z, y.w);
             }
-        }
-        lds_barrier(); // B1: every thread holds its samples, the raw tile may be overwritten by the prefixes
-        // ---- phase 1 (f32): products once per sample, exclusive local prefixes
-        float rqr = 0.f, rqi = 0.f, re = 0.f;
-        if (has_samples) {
             float4 *wq4 = reinterpret_cast<float4 *>(lq + n0);
             float2 *we2 = reinterpret_cast<float2 *>(le + n0);
 #pragma unroll
@@ -385,7 +384,8 @@ __global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
         }
         const float iqr = wave_scan_f(rqr), iqi = wave_scan_f(rqi), ie = wave_scan_f(re);
         if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
-        lds_barrier(); // B2
+        lds_barrier(); // B2: wave totals visible; every thread is done with the raw samples
+        if (more && p.debug != 1 && p.debug != 4) stage(f + fstep); // next frame's LDS-DMA flies behind the bases, phase 2A and the tail
         float wq = lane < NW ? wtot[lane * 4 + 0] : 0.f, wi = lane < NW ? wtot[lane * 4 + 1] : 0.f,
               we = lane < NW ? wtot[lane * 4 + 2] : 0.f;
         float sq = wq, si = wi, se = we;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
         bq[tid] = make_float2(mybqr, mybqi);
         be[tid] = mybe;
         lds_barrier(); // B3
-        if (p.debug == 2) { if (more && p.debug != 1) stage(f + fstep); continue; }
+        if (p.debug == 2) continue;
 
         // ---- phase 2A (f32): metric at this thread's 10 lags, two lags per packed op
         float2 mp[C / 2];     // f32 metric of lags (2i, 2i+1); -1 where the lag is not searched / has no energy
@@ -441,10 +441,9 @@ __global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
                 if (hi != INT_MAX) atomicMin(&S[1], hi);
             }
         }
-        lds_barrier(); // B4: prefixes are dead from here on
+        lds_barrier(); // B4
+        if (more && p.debug == 4) stage(f + fstep);
         const int c_lo = S[0], c_hi = S[1];
-        // single raw tile: 3 workgroups per CU (more independent waves) measured faster than a double buffer with 2
-        if (more && p.debug != 1) stage(f + fstep);
         if (p.debug == 3) continue;
         if (c_lo == INT_MAX || c_lo != c_hi) {
             if (tid == 0) {
@@ -470,6 +469,469 @@ __global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
             p.rec[f] = ScRec{1, d1, nw, 0};
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_sc_slide: third generation of the filter.  Same contract (f32 filter, exact f64 decisions in k_sc_finish), but NO
+// per-sample prefix arrays: LDS holds only the raw samples (18 KB for a 2176-sample frame) and a per-chunk prefix
+// (3 KB), so six workgroups share a CU instead of three.
+//   phase 1: thread t sums q = conj(r[n]) r[n+L] and e = |r[n]|^2 over its 10 samples; one workgroup scan turns the
+//            chunk totals into exclusive chunk prefixes Bq / Be;
+//   phase 2: P, E, R at the thread's first lag are chunk-prefix differences; the other 9 lags SLIDE the window:
+//            P += q[d+W] - q[d], E += e[d+W] - e[d], R += e[d+W+L] - e[d+L], products recomputed from the raw samples
+//            (4 x 80 B of LDS reads per thread instead of 120 B of prefix stores + 320 B of prefix reads).
+template <int WG, int OCC>
+__global__ __launch_bounds__(WG, OCC) void k_sc_slide(ScFastParams p) {
+    constexpr int C = 10, NW = WG / 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int L = p.L, W = p.W, n = p.n_lags;
+    const int nstaged = 2 * p.n16;
+    const int ns = (nstaged + C - 1) / C * C;               // whole 10-sample chunks
+    cf *raw = reinterpret_cast<cf *>(smem);                 // [ns + L]; entries past the staged samples stay 0
+    float2 *bq = reinterpret_cast<float2 *>(raw + ns + L);  // [WG] exclusive chunk prefix of q
+    float *be = reinterpret_cast<float *>(bq + WG);         // [WG] ... of e
+    float *wtot = be + WG;                                  // [NW][4] wave totals
+    int *sh = reinterpret_cast<int *>(wtot + 4 * NW);       // [2][8] per-parity: lo, hi
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cL = L / C, cW = W / C;
+    const unsigned raw_lds = lds_addr(raw);
+    const int n0 = tid * C;
+    const bool has_samples = n0 < ns;
+    const bool live = n0 < n; // this thread owns at least one searched lag (implies tid + cW + cL < WG)
+
+    auto stage = [&](long long fr) { // this wave's 1-KiB pieces of frame fr -> raw
+        const char *sbase = reinterpret_cast<const char *>(p.in + fr * p.frame_stride);
+        for (int piece = wave; piece * 64 < p.n16; piece += NW) {
+            const int i = piece * 64 + lane;
+            if (i < p.n16) glds16(sbase, (unsigned)i * 16u, raw_lds + (unsigned)piece * 1024u);
+        }
+    };
+    for (int i = nstaged + tid; i < ns + L; i += WG) raw[i] = make_float2(0.f, 0.f); // never written by the DMA
+    long long f = blockIdx.x;
+    const long long fstep = gridDim.x;
+    if (f < p.n_frames) stage(f);
+    if (tid < 16) sh[tid] = (tid & 7) < 2 ? INT_MAX : 0;
+    int cur = 0;
+
+    for (; f < p.n_frames; f += fstep, cur ^= 1) {
+        int *S = sh + cur * 8;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
+        lds_barrier();                                   // B0: ... and everyone else's
+        const bool more = f + fstep < p.n_frames;
+        if (tid < 8) sh[(cur ^ 1) * 8 + tid] = tid < 2 ? INT_MAX : 0;
+        // ---- phase 1 (f32): chunk totals of q and e
+        float tqr = 0.f, tqi = 0.f, te = 0.f;
+        const float4 *pa = reinterpret_cast<const float4 *>(raw + n0), *pb = reinterpret_cast<const float4 *>(raw + n0 + L);
+        if (has_samples) {
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) {
+                const float4 x = pa[i], y = pb[i];
+                tqr += x.x * y.x + x.y * y.y; tqi += x.x * y.y - x.y * y.x; te += x.x * x.x + x.y * x.y;
+                tqr += x.z * y.z + x.w * y.w; tqi += x.z * y.w - x.w * y.z; te += x.z * x.z + x.w * x.w;
+            }
+        }
+        const float iqr = wave_scan_f(tqr), iqi = wave_scan_f(tqi), ie = wave_scan_f(te);
+        if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
+        lds_barrier(); // B2: wave totals visible
+        float wq = lane < NW ? wtot[lane * 4 + 0] : 0.f, wi = lane < NW ? wtot[lane * 4 + 1] : 0.f,
+              we = lane < NW ? wtot[lane * 4 + 2] : 0.f;
+        float sq = wq, si = wi, se = we;
+        sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
+        sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
+        const float mybqr = (iqr - tqr) + (readlane_f(sq, wave) - readlane_f(wq, wave));
+        const float mybqi = (iqi - tqi) + (readlane_f(si, wave) - readlane_f(wi, wave));
+        const float mybe = (ie - te) + (readlane_f(se, wave) - readlane_f(we, wave));
+        bq[tid] = make_float2(mybqr, mybqi);
+        be[tid] = mybe;
+        lds_barrier(); // B3: chunk prefixes visible
+        if (p.debug == 2) { lds_barrier(); if (more) stage(f + fstep); continue; }
+
+        // ---- phase 2 (f32): metric at this thread's 10 lags by sliding the window
+        float mp[C];           // f32 metric; -1 where the lag is not searched / has no energy
+        bool unsafe_t = false; // this thread's lags are not trusted (prefix energy >> window energy): decided exactly
+#pragma unroll
+        for (int j = 0; j < C; ++j) mp[j] = -1.f;
+        if (live) {
+            const float2 b1 = bq[tid + cW];
+            float Pr = b1.x - mybqr, Pi = b1.y - mybqi;
+            const float etop = be[tid + cW + cL];
+            float E = be[tid + cW] - mybe, R = etop - be[tid + cL];
+            const float4 *pc = reinterpret_cast<const float4 *>(raw + n0 + W), *pd = reinterpret_cast<const float4 *>(raw + n0 + W + L);
+            float emin = 3.0e38f, mmax = -1.f;
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) {
+                const float4 a = pa[i], b = pb[i], c = pc[i], d = pd[i];
+                {
+                    const float den = E * R;
+                    const bool ok = den > 0.f && n0 + 2 * i < n;
+                    mp[2 * i] = ok ? (Pr * Pr + Pi * Pi) * __builtin_amdgcn_rcpf(den) : -1.f;
+                    emin = fminf(emin, ok ? fminf(E, R) : 3.0e38f);
+                    mmax = fmaxf(mmax, mp[2 * i]);
+                    Pr += c.x * d.x + c.y * d.y - a.x * b.x - a.y * b.y;
+                    Pi += c.x * d.y - c.y * d.x - a.x * b.y + a.y * b.x;
+                    E += c.x * c.x + c.y * c.y - a.x * a.x - a.y * a.y;
+                    R += d.x * d.x + d.y * d.y - b.x * b.x - b.y * b.y;
+                }
+                {
+                    const float den = E * R;
+                    const bool ok = den > 0.f && n0 + 2 * i + 1 < n;
+                    mp[2 * i + 1] = ok ? (Pr * Pr + Pi * Pi) * __builtin_amdgcn_rcpf(den) : -1.f;
+                    emin = fminf(emin, ok ? fminf(E, R) : 3.0e38f);
+                    mmax = fmaxf(mmax, mp[2 * i + 1]);
+                    Pr += c.z * d.z + c.w * d.w - a.z * b.z - a.w * b.w;
+                    Pi += c.z * d.w - c.w * d.z - a.z * b.w + a.w * b.z;
+                    E += c.z * c.z + c.w * c.w - a.z * a.z - a.w * a.w;
+                    R += d.z * d.z + d.w * d.w - b.z * b.z - b.w * b.w;
+                }
+            }
+            unsafe_t = etop > SC_UNSAFE_RATIO * emin; // emin stays huge when no lag has energy
+            if (unsafe_t || mmax >= p.thr_lo) {        // only threads near the packet scan their lags for the crossing
+                int lo = INT_MAX, hi = INT_MAX;
+#pragma unroll
+                for (int j = C - 1; j >= 0; --j) {
+                    const float m = mp[j];
+                    if (m >= 0.f && (unsafe_t || m >= p.thr_lo)) lo = n0 + j;
+                    if (m >= 0.f && !unsafe_t && m >= p.thr_hi) hi = n0 + j;
+                }
+                if (lo != INT_MAX) atomicMin(&S[0], lo);
+                if (hi != INT_MAX) atomicMin(&S[1], hi);
+            }
+        }
+        lds_barrier(); // B4: crossing known; the raw samples are dead
+        if (more) stage(f + fstep);
+        const int c_lo = S[0], c_hi = S[1];
+        if (p.debug == 3) continue;
+        if (c_lo == INT_MAX || c_lo != c_hi) {
+            if (tid == 0) {
+                p.d_hat[f] = -1;
+                if (c_lo == INT_MAX) p.rec[f] = ScRec{-1, 0, 0, 0}; // nothing reaches the threshold: no packet
+                else { p.rec[f] = ScRec{-2, 0, 0, 0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; } // ambiguous crossing: redo in f64
+            }
+            continue;
+        }
+        const int d1 = c_lo;
+        // ---- hand the peak window to the finish kernel: f32 metric of every lag of [d1, d1 + W] (exact compare there)
+        if (live && n0 + C > d1 && n0 <= d1 + W) {
+            float *mw = p.mwin + f * p.wstride;
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const int d = n0 + j;
+                if (d >= d1 && d <= d1 + W && d < n) mw[d - d1] = (unsafe_t && mp[j] >= 0.f) ? __builtin_inff() : mp[j];
+            }
+        }
+        if (tid == 0) {
+            const int nw = n - d1 < W + 1 ? n - d1 : W + 1;
+            p.rec[f] = ScRec{1, d1, nw, 0};
+        }
+    }
+}
+static size_t sc_slide_lds_bytes(int L, int wg, long long frame_len) { // raw samples + chunk prefixes
+    long long ns = ((frame_len + 1) / 2 * 2 + 9) / 10 * 10;
+    if (ns > (long long)wg * 10) ns = (long long)wg * 10;
+    return (size_t)(ns + L) * sizeof(float2) + (size_t)wg * (sizeof(float2) + sizeof(float)) + 16 * sizeof(float) + 16 * sizeof(int) + 16;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_sc_cf: coarse-then-fine filter (fourth generation).  The per-lag metric is only ever needed around the packet:
+// at the first threshold crossing and over the W + 1 lags after it.  So
+//   phase 1  (all threads)  chunk totals of q = conj(r[n]) r[n+L] and e = |r[n]|^2 over 10-sample chunks, one
+//            workgroup scan -> exclusive chunk prefixes Bq / Be and the chunk energies Te in LDS (4 KB);
+//   coarse   (all threads)  P, E, R at the chunk's first lag are prefix differences.  Over the chunk's 10 lags
+//                |P(d)| <= |P0| + 1/2 (Te[c] + Te[c+L] + Te[c+W] + Te[c+W+L])      (|q[n]| <= (e[n] + e[n+L]) / 2)
+//                E(d) >= E0 - Te[c],   R(d) >= R0 - Te[c+L]
+//            so M(d) <= ub^2 / (Elo Rlo): chunks whose bound stays below the threshold (with the f32 error of the
+//            prefix differences, <= 4e-6 x the largest prefix, charged against them) CANNOT hold a crossing and are
+//            never looked at again.  On noise and on data symbols the bound is ~0.03, so only the chunks where the
+//            periodic header enters the window are flagged;
+//   fine     (ONE wavefront, rotating per frame so the four SIMDs share the work)  the 64 chunks from the first
+//            flagged one on: slide the window over the chunk's 10 lags from the raw samples in LDS (as k_sc_slide),
+//            first crossing by ballot, window maximum by a wavefront reduction, <= 4 candidates re-evaluated in f64
+//            from the same LDS samples, results written directly (no window hand-off, no finish kernel).
+// Anything the filter cannot settle (ambiguous crossing, > 4 candidates) goes to the slow list as before.
+// LDS: raw samples (18 KB for a 2176-sample frame) + 4.3 KB -> seven workgroups per CU by LDS.
+__device__ __forceinline__ float wave_max_f(float x) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) x = fmaxf(x, __shfl_xor(x, s, 64));
+    return x;
+}
+// Four f64 wavefront sums for the price of seven shuffles: the lanes split the four quantities between them while
+// they fold (xor 32: two each, xor 16: one each, then 8 4 2 1).  Totals land in lanes 0 / 16 / 32 / 48; fixed order.
+__device__ __forceinline__ void wave_sum4_d(double &xr, double &xi, double &xe, double &xq, int lane) {
+    const bool h5 = lane & 32, h4 = lane & 16;
+    double k0 = h5 ? xe : xr, k1 = h5 ? xq : xi;
+    const double s0 = h5 ? xr : xe, s1 = h5 ? xi : xq;
+    k0 += __shfl_xor(s0, 32, 64);
+    k1 += __shfl_xor(s1, 32, 64);
+    double k = h4 ? k1 : k0;
+    const double sx = h4 ? k0 : k1;
+    k += __shfl_xor(sx, 16, 64);
+#pragma unroll
+    for (int s = 8; s >= 1; s >>= 1) k += __shfl_xor(k, s, 64);
+    xr = readlane_d(k, 0); xi = readlane_d(k, 16); xe = readlane_d(k, 32); xq = readlane_d(k, 48);
+}
+struct ScExact { double pr, pi, num, den; }; // exact sums at the chosen lag; k_sc_post turns them into CFO and metric
+
+// Exact decision among <= 4 candidate lags of one frame (one wavefront; samples in LDS): f64 sums over the window,
+// first maximum wins.  Out of line: it runs once per frame in one wavefront of four.
+__device__ __attribute__((noinline)) void sc_exact_pick(const cf *raw, int c0, int c1, int c2, int c3, int cnt, int L, int W, int lane,
+                                                        int32_t *d_hat, ScExact *ex) {
+    Cand best = Cand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
+    for (int i = 0; i < cnt; ++i) {
+        const int d = i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3;
+        double xr = 0, xi = 0, xe = 0, xq = 0;
+        for (int m = lane; m < W; m += 64) {
+            const cf sa = raw[d + m], sb = raw[d + m + L];
+            const double ar = sa.x, ai = sa.y, br = sb.x, bi = sb.y;
+            xr += ar * br + ai * bi;
+            xi += ar * bi - ai * br;
+            xe += ar * ar + ai * ai;
+            xq += br * br + bi * bi;
+        }
+        wave_sum4_d(xr, xi, xe, xq, lane);
+        const double xn = xr * xr + xi * xi, xd = xe * xq;
+        if (xd > 0.0) { // first maximum wins: strictly greater replaces, ties go to the lower lag
+            const double lhs = xn * best.den, rhs = best.num * xd;
+            if (lhs > rhs || (lhs == rhs && d < best.lag)) best = Cand{xn, xd, xr, xi, d};
+        }
+    }
+    if (lane == 0) {
+        const bool found = best.lag != INT_MAX;
+        *d_hat = found ? best.lag : -1;
+        *ex = ScExact{best.pr, best.pi, found ? best.num : 0.0, best.den};
+    }
+}
+// CFO and metric of every frame the filter settled, one LANE per frame (the f64 atan2 and division cost the same for
+// 64 frames as for one).  Frames without a packet and frames on the slow list (rewritten by k_sc_tile) get zeros.
+__global__ __launch_bounds__(256) void k_sc_post(const int32_t *d_hat, const ScExact *ex, long long n_frames, int L, double *f_delta,
+                                                 float *metric) {
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_frames) return;
+    const bool found = d_hat[f] >= 0;
+    ScExact e = ScExact{1.0, 0.0, 0.0, 1.0};
+    if (found) e = ex[f];
+    if (f_delta) f_delta[f] = found ? atan2(e.pi, e.pr) / (double)L : 0.0;
+    if (metric) metric[f] = found ? (float)(e.num / e.den) : 0.f;
+}
+
+template <int WG, int OCC>
+__global__ __launch_bounds__(WG, OCC) void k_sc_cf(ScFastParams p) {
+    constexpr int C = 10, NW = WG / 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int L = p.L, W = p.W, n = p.n_lags;
+    const int nstaged = 2 * p.n16;
+    const int ns = (nstaged + C - 1) / C * C;               // whole 10-sample chunks
+    cf *raw = reinterpret_cast<cf *>(smem);                 // [ns + L]; entries past the staged samples stay 0
+    float2 *bq = reinterpret_cast<float2 *>(raw + ns + L);  // [WG + 2] exclusive chunk prefix of q ([WG] = total)
+    float *be = reinterpret_cast<float *>(bq + WG + 2);     // [WG + 2] ... of e
+    float *tes = be + WG + 2;                               // [WG] chunk energies
+    float *wtot = tes + WG;                                 // [NW][4] wave totals
+    unsigned long long *flg = reinterpret_cast<unsigned long long *>(wtot + 4 * NW); // [NW] flagged chunks, one bit per thread
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cL = L / C, cW = W / C;
+    const unsigned raw_lds = lds_addr(raw);
+    const int n0 = tid * C;
+    const bool has_samples = n0 < ns;
+    const bool live = n0 < n; // this thread owns at least one searched lag (implies tid + cW + cL < WG)
+    const float thr_c = p.thr_lo * (1.f - SC_EPS);
+
+    auto stage = [&](long long fr) { // this wave's 1-KiB pieces of frame fr -> raw
+        const char *sbase = reinterpret_cast<const char *>(p.in + fr * p.frame_stride);
+        for (int piece = wave; piece * 64 < p.n16; piece += NW) {
+            const int i = piece * 64 + lane;
+            if (i < p.n16) glds16(sbase, (unsigned)i * 16u, raw_lds + (unsigned)piece * 1024u);
+        }
+    };
+    auto to_slow = [&](long long fr) { p.d_hat[fr] = -1; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)fr; };
+
+    for (int i = nstaged + tid; i < ns + L; i += WG) raw[i] = make_float2(0.f, 0.f); // never written by the DMA
+    long long f = blockIdx.x;
+    const long long fstep = gridDim.x;
+    if (f < p.n_frames) stage(f);
+    int it = blockIdx.x;
+
+    for (; f < p.n_frames; f += fstep, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
+        lds_barrier();                                   // B0: ... and everyone else's
+        const bool more = f + fstep < p.n_frames;
+        // ---- phase 1 (f32): chunk totals of q and e
+        float tqr = 0.f, tqi = 0.f, te = 0.f;
+        if (has_samples) {
+            const float4 *pa = reinterpret_cast<const float4 *>(raw + n0), *pb = reinterpret_cast<const float4 *>(raw + n0 + L);
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) {
+                const float4 x = pa[i], y = pb[i];
+                tqr += x.x * y.x + x.y * y.y; tqi += x.x * y.y - x.y * y.x; te += x.x * x.x + x.y * x.y;
+                tqr += x.z * y.z + x.w * y.w; tqi += x.z * y.w - x.w * y.z; te += x.z * x.z + x.w * x.w;
+            }
+        }
+        tes[tid] = te;
+        const float iqr = wave_scan_f(tqr), iqi = wave_scan_f(tqi), ie = wave_scan_f(te);
+        if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
+        lds_barrier(); // B2: wave totals visible
+        float wq = lane < NW ? wtot[lane * 4 + 0] : 0.f, wi = lane < NW ? wtot[lane * 4 + 1] : 0.f,
+              we = lane < NW ? wtot[lane * 4 + 2] : 0.f;
+        float sq = wq, si = wi, se = we;
+        sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
+        sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
+        const float mybqr = (iqr - tqr) + (readlane_f(sq, wave) - readlane_f(wq, wave));
+        const float mybqi = (iqi - tqi) + (readlane_f(si, wave) - readlane_f(wi, wave));
+        const float mybe = (ie - te) + (readlane_f(se, wave) - readlane_f(we, wave));
+        bq[tid] = make_float2(mybqr, mybqi);
+        be[tid] = mybe;
+        if (tid == WG - 1) { bq[WG] = make_float2(mybqr + tqr, mybqi + tqi); be[WG] = mybe + te; } // a backward slide may start here
+        lds_barrier(); // B3: chunk prefixes visible
+        if (p.debug == 2) { lds_barrier(); if (more) stage(f + fstep); continue; }
+
+        // ---- coarse pass: can any of this chunk's 10 lags reach the threshold?
+        bool flag = false;
+        if (live) {
+            const float2 b1 = bq[tid + cW];
+            const float Pr = b1.x - mybqr, Pi = b1.y - mybqi;
+            const float eL = tes[tid + cL], eW = tes[tid + cW], eWL = tes[tid + cW + cL];
+            const float btop = be[tid + cW + cL];
+            const float E0 = be[tid + cW] - mybe, R0 = btop - be[tid + cL];
+            const float dlt = (btop + eWL) * 4e-6f;                       // f32 error of a prefix difference
+            const float ub = __builtin_sqrtf(Pr * Pr + Pi * Pi) * 1.000001f + 0.5f * (te + eL + eW + eWL) + 2.f * dlt;
+            const float Elo = E0 - te - dlt, Rlo = R0 - eL - dlt;
+            flag = ub > 0.f && !(Elo > 0.f && Rlo > 0.f && ub * ub < thr_c * Elo * Rlo);
+        }
+        const unsigned long long fm = __ballot(flag);
+        if (lane == 0) flg[wave] = fm;
+        lds_barrier(); // B4: flags visible
+        unsigned long long fmask[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const unsigned long long v = flg[w];
+            fmask[w] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+        }
+        auto next_flag = [&](int pos) -> int { // first flagged chunk >= pos, or -1 (wave-uniform)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if (pos >= (w + 1) * 64) continue;
+                unsigned long long mm = fmask[w];
+                if (pos > w * 64) mm &= ~0ull << (pos - w * 64);
+                if (mm) return w * 64 + __ffsll((long long)mm) - 1;
+            }
+            return -1;
+        };
+        int gs = next_flag(0);
+        if (gs < 0) { // no chunk can reach the threshold: no packet
+            if (tid == 0) p.d_hat[f] = -1;
+            if (more) stage(f + fstep);   // every wave is done with the raw samples (phase 1 ended before B2)
+            continue;
+        }
+        if (p.debug == 3) { lds_barrier(); if (more) stage(f + fstep); continue; }
+
+        // ---- fine pass: one wavefront, the 32 chunks (320 lags) from the first flagged one; lane 2k slides forward from
+        //      chunk boundary k over lags +0..+4, lane 2k+1 slides BACKWARD from boundary k+1 over lags +9..+5
+        if (wave == (it & (NW - 1))) {
+            const int hh = lane & 1;
+            const float sgn = hh ? -1.f : 1.f;
+            for (;;) {
+                const int c = gs + (lane >> 1), m0 = c * C;
+                const bool lv = m0 + 5 * hh < n; // implies c + hh + cW + cL < WG
+                float mp[5];                      // metric of round k: lag m0 + k (forward) or m0 + 9 - k (backward)
+                bool unsafe_t = false;
+                int lo = INT_MAX, hi = INT_MAX;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) mp[k] = -1.f;
+                if (lv) {
+                    const int cb = c + hh;
+                    const float2 q0 = bq[cb], q1 = bq[cb + cW];
+                    float Pr = q1.x - q0.x, Pi = q1.y - q0.y;
+                    const float etop = be[cb + cW + cL];
+                    float E = be[cb + cW] - be[cb], R = etop - be[cb + cL];
+                    float emin = 3.0e38f, mmax = -1.f;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        // update to this round's lag: low sample x of the step (forward k = 0 sits on the boundary: no step)
+                        const int x = hh ? m0 + 9 - k : m0 + (k > 0 ? k - 1 : 0);
+                        const float w = (hh || k > 0) ? sgn : 0.f;
+                        const cf a = raw[x], b = raw[x + L], cc = raw[x + W], d = raw[x + W + L];
+                        Pr += w * (cc.x * d.x + cc.y * d.y - a.x * b.x - a.y * b.y);
+                        Pi += w * (cc.x * d.y - cc.y * d.x - a.x * b.y + a.y * b.x);
+                        E += w * (cc.x * cc.x + cc.y * cc.y - a.x * a.x - a.y * a.y);
+                        R += w * (d.x * d.x + d.y * d.y - b.x * b.x - b.y * b.y);
+                        const int lag = hh ? m0 + 9 - k : m0 + k;
+                        const float den = E * R;
+                        const bool ok = den > 0.f && lag < n;
+                        mp[k] = ok ? (Pr * Pr + Pi * Pi) * __builtin_amdgcn_rcpf(den) : -1.f;
+                        emin = fminf(emin, ok ? fminf(E, R) : 3.0e38f);
+                        mmax = fmaxf(mmax, mp[k]);
+                    }
+                    unsafe_t = etop > SC_UNSAFE_RATIO * emin; // emin stays huge when no lag has energy
+                    if (unsafe_t || mmax >= p.thr_lo) {
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            const int kk = hh ? k : 4 - k;           // visit this lane's lags in decreasing order
+                            const int lag = hh ? m0 + 9 - kk : m0 + kk;
+                            const float m = mp[kk];
+                            if (m >= 0.f && (unsafe_t || m >= p.thr_lo)) lo = lag;
+                            if (m >= 0.f && !unsafe_t && m >= p.thr_hi) hi = lag;
+                        }
+                    }
+                }
+                if (p.debug == 5) break;
+                const unsigned long long lo_m = __ballot(lo != INT_MAX), hi_m = __ballot(hi != INT_MAX);
+                if (lo_m == 0) { // nothing crosses in these 32 chunks: on to the next flagged chunk
+                    gs = next_flag(gs + 32);
+                    if (gs < 0) { if (lane == 0) p.d_hat[f] = -1; break; }
+                    continue;
+                }
+                const int c_lo = __builtin_amdgcn_readlane(lo, __ffsll((long long)lo_m) - 1);
+                const int c_hi = hi_m ? __builtin_amdgcn_readlane(hi, __ffsll((long long)hi_m) - 1) : INT_MAX;
+                if (c_lo != c_hi) { if (lane == 0) to_slow(f); break; } // ambiguous crossing: redo in f64
+                const int d1 = c_lo;
+                const int dend = d1 + W < n - 1 ? d1 + W : n - 1;        // last lag of the peak window
+                if (dend >= (gs + 32) * C) { gs = d1 / C; continue; }    // window not covered: restart at the crossing's chunk
+                // window maximum over the trusted lags, then the candidates within 2 EPS of it (+ the untrusted ones)
+                float lmax = 0.f;
+                bool inw[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int lag = hh ? m0 + 9 - k : m0 + k;
+                    inw[k] = lag >= d1 && lag <= dend && mp[k] >= 0.f;
+                    if (inw[k] && !unsafe_t) lmax = fmaxf(lmax, mp[k]);
+                }
+                const float mcut = wave_max_f(lmax) * (1.f - 2.f * SC_EPS);
+                unsigned cm = 0; // this lane's candidate rounds
+#pragma unroll
+                for (int k = 0; k < 5; ++k) cm |= (inw[k] && (unsafe_t || mp[k] >= mcut)) ? 1u << k : 0u;
+                int cand[SC_MAXCAND] = {0, 0, 0, 0}; // only ever indexed statically
+                int cnt = 0;
+                unsigned long long any = __ballot(cm != 0);
+                while (any && cnt <= SC_MAXCAND) { // wave-uniform: one candidate per trip (typically one trip)
+                    const int l = __ffsll((long long)any) - 1;
+                    const unsigned mk = (unsigned)__builtin_amdgcn_readlane((int)cm, l);
+                    const int k = __ffs((int)mk) - 1;
+                    const int lag = (gs + (l >> 1)) * C + ((l & 1) ? 9 - k : k);
+#pragma unroll
+                    for (int t = 0; t < SC_MAXCAND; ++t) cand[t] = cnt == t ? lag : cand[t];
+                    ++cnt;
+                    if (lane == l) cm &= cm - 1;
+                    any = __ballot(cm != 0);
+                }
+                if (cnt == 0) { if (lane == 0) p.d_hat[f] = -1; break; }
+                if (cnt > SC_MAXCAND) { if (lane == 0) to_slow(f); break; }
+                if (p.debug == 4) break;
+                sc_exact_pick(raw, cand[0], cand[1], cand[2], cand[3], cnt, L, W, lane, p.d_hat + f, p.exact + f);
+                break;
+            }
+        }
+        lds_barrier(); // B5: the fine wavefront is done with the raw samples
+        if (more) stage(f + fstep);
+    }
+}
+static size_t sc_cf_lds_bytes(int L, int wg, long long frame_len) { // raw samples + chunk prefixes, energies, flags
+    long long ns = ((frame_len + 1) / 2 * 2 + 9) / 10 * 10;
+    if (ns > (long long)wg * 10) ns = (long long)wg * 10;
+    return (size_t)(ns + L) * sizeof(float2) + (size_t)(wg + 2) * (sizeof(float2) + sizeof(float)) + (size_t)wg * sizeof(float) +
+           16 * sizeof(float) + 64 + 16;
 }
 
 // Exact decision for the frames the filter settled: one wavefront per frame.  It takes the f32 window maximum, keeps the
@@ -546,10 +1008,11 @@ __global__ __launch_bounds__(256) void k_sc_finish(const ScRec *rec, const float
     }
 }
 
-static size_t sc_fast_lds_bytes(int L, int wg) { // k_sc_fast2: raw tile (aliased by the q prefixes) + e prefixes + bases
-    const size_t n = (size_t)wg * 10;
-    return (n + L) * sizeof(float2) + n * sizeof(float) + (size_t)wg * (sizeof(float2) + sizeof(float)) +
-           16 * sizeof(float) * 2 + 16 * sizeof(int) + 16;
+static size_t sc_fast_lds_bytes(int L, int wg, long long frame_len) { // raw samples + q and e prefixes + bases
+    long long n = ((frame_len + 1) / 2 * 2 + 9) / 10 * 10; // staged samples in whole 10-sample chunks (k_sc_fast2: ns)
+    if (n > (long long)wg * 10) n = (long long)wg * 10;
+    return (size_t)(n + L) * sizeof(float2) + (size_t)n * (sizeof(float2) + sizeof(float)) +
+           (size_t)wg * (sizeof(float2) + sizeof(float)) + 16 * sizeof(float) * 2 + 16 * sizeof(int) + 16;
 }
 // smallest workgroup (128 / 256 threads, 10 samples each) whose tile covers the searched lags plus the window
 static int sc_fast_pick_wg(const ScParams &p) {
@@ -562,18 +1025,19 @@ bool sc_fast_ok(const ScParams &p) {
     // one tile per frame, 10 | L, 16-byte aligned even-length frames
     const int wg = sc_fast_pick_wg(p);
     return p.mode == 0 && wg != 0 && p.L % 10 == 0 && p.W % 10 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 &&
-           (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L, wg) <= 64 * 1024;
+           (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L, wg, p.frame_len) <= 64 * 1024;
 }
 static int sc_wstride(int W) { return ((W + 1 + 63) / 64) * 64; }
 size_t sc_fast_workspace_bytes(long long n_frames, int W) {
-    return (size_t)n_frames * (sizeof(ScRec) + sizeof(int32_t) + sizeof(float) * (size_t)sc_wstride(W)) + 64;
+    static_assert(sizeof(ScExact) >= sizeof(ScRec), "k_sc_cf's records alias the previous generation's");
+    return (size_t)n_frames * (sizeof(ScExact) + sizeof(int32_t) + sizeof(float) * (size_t)sc_wstride(W)) + 64;
 }
 
 // p.mode == 0, p.tiles_per_frame == 1.  workspace: sc_fast_workspace_bytes(n_frames) bytes of device memory.
 hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st) {
     if (p.n_frames <= 0) return hipSuccess;
     const int wg = sc_fast_pick_wg(p);
-    const size_t lds = sc_fast_lds_bytes(p.L, wg);
+    const size_t lds = sc_fast_lds_bytes(p.L, wg, p.frame_len);
     ScRec *rec = reinterpret_cast<ScRec *>(workspace);
     const int wstride = sc_wstride(p.W);
     float *mwin = reinterpret_cast<float *>(rec + p.n_frames);
@@ -597,12 +1061,47 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     if (per_cu > 768 / wg) per_cu = 768 / wg; // ~150 VGPRs -> 3 waves per SIMD -> 12 waves per CU (4 with spills measured slower)
     long long grid = (long long)num_cu * per_cu;
     if (grid > p.n_frames) grid = p.n_frames;
-    if (wg == 256) hipLaunchKernelGGL(k_sc_fast2<256>, dim3((unsigned)grid), dim3(256), lds, st, q);
+    static const int slide = [] { const char *e = getenv("OFDM_SC_SLIDE"); return e ? atoi(e) : 0; }(); // A/B knob: workgroups per CU
+    static const int cfk = [] { const char *e = getenv("OFDM_SC_CF"); return e ? atoi(e) : 5; }(); // workgroups per CU; 0 = previous generation
+    if (cfk > 0 && p.W + 2 * 10 <= 320) { // the fine pass looks at 320 lags from the first flagged chunk
+        ScExact *exact = reinterpret_cast<ScExact *>(workspace); // aliases rec / mwin of the previous generation
+        q.exact = exact;
+        q.slow_count = reinterpret_cast<int32_t *>(exact + p.n_frames);
+        q.slow_list = q.slow_count + 4;
+        slow_count = q.slow_count; slow_list = q.slow_list;
+        if ((e = hipMemsetAsync(slow_count, 0, 16, st)) != hipSuccess) return e;
+        const size_t l4 = sc_cf_lds_bytes(p.L, wg, p.frame_len);
+        long long pc = (long long)(160 * 1024) / (long long)l4;
+        if (pc > cfk) pc = cfk;
+        grid = (long long)num_cu * pc;
+        if (grid > p.n_frames) grid = p.n_frames;
+        if (wg == 256) {
+            if (cfk >= 6) hipLaunchKernelGGL((k_sc_cf<256, 6>), dim3((unsigned)grid), dim3(256), l4, st, q);
+            else if (cfk == 5) hipLaunchKernelGGL((k_sc_cf<256, 5>), dim3((unsigned)grid), dim3(256), l4, st, q);
+            else hipLaunchKernelGGL((k_sc_cf<256, 4>), dim3((unsigned)grid), dim3(256), l4, st, q);
+        } else hipLaunchKernelGGL((k_sc_cf<128, 5>), dim3((unsigned)grid), dim3(128), l4, st, q);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_sc_post, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, p.d_hat, exact, p.n_frames, p.L,
+                           p.f_delta, p.metric);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        goto slow_pass;
+    }
+    if (slide > 0 && wg == 256) {
+        const size_t l3 = sc_slide_lds_bytes(p.L, wg, p.frame_len);
+        long long pc = (long long)(160 * 1024) / (long long)l3;
+        if (pc > slide) pc = slide;
+        grid = (long long)num_cu * pc;
+        if (grid > p.n_frames) grid = p.n_frames;
+        if (slide >= 6) hipLaunchKernelGGL((k_sc_slide<256, 6>), dim3((unsigned)grid), dim3(256), l3, st, q);
+        else if (slide == 5) hipLaunchKernelGGL((k_sc_slide<256, 5>), dim3((unsigned)grid), dim3(256), l3, st, q);
+        else hipLaunchKernelGGL((k_sc_slide<256, 4>), dim3((unsigned)grid), dim3(256), l3, st, q);
+    } else if (wg == 256) hipLaunchKernelGGL(k_sc_fast2<256>, dim3((unsigned)grid), dim3(256), lds, st, q);
     else hipLaunchKernelGGL(k_sc_fast2<128>, dim3((unsigned)grid), dim3(128), lds, st, q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((p.n_frames + 3) / 4)), dim3(256), 0, st, rec, mwin, wstride, p.in, p.n_frames,
                        p.frame_stride, p.L, p.W, p.d_hat, p.f_delta, p.metric, slow_list, slow_count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+slow_pass:
     // frames the filter could not settle: all-f64 kernel over the device-side list (usually empty)
     ScParams s = p;
     s.slow_list = slow_list; s.slow_count = slow_count; s.tiles_per_frame = 1; s.mode = 0;
