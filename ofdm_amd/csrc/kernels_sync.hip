@@ -651,45 +651,52 @@ static size_t sc_slide_lds_bytes(int L, int wg, long long frame_len) { // raw sa
 //            from the same LDS samples, results written directly (no window hand-off, no finish kernel).
 // Anything the filter cannot settle (ambiguous crossing, > 4 candidates) goes to the slow list as before.
 // LDS: raw samples (18 KB for a 2176-sample frame) + 4.3 KB -> seven workgroups per CU by LDS.
-__device__ __forceinline__ float wave_max_f(float x) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) x = fmaxf(x, __shfl_xor(x, s, 64));
-    return x;
-}
-// Four f64 wavefront sums for the price of seven shuffles: the lanes split the four quantities between them while
-// they fold (xor 32: two each, xor 16: one each, then 8 4 2 1).  Totals land in lanes 0 / 16 / 32 / 48; fixed order.
-__device__ __forceinline__ void wave_sum4_d(double &xr, double &xi, double &xe, double &xq, int lane) {
-    const bool h5 = lane & 32, h4 = lane & 16;
-    double k0 = h5 ? xe : xr, k1 = h5 ? xq : xi;
-    const double s0 = h5 ? xr : xe, s1 = h5 ? xi : xq;
-    k0 += __shfl_xor(s0, 32, 64);
-    k1 += __shfl_xor(s1, 32, 64);
-    double k = h4 ? k1 : k0;
-    const double sx = h4 ? k0 : k1;
-    k += __shfl_xor(sx, 16, 64);
-#pragma unroll
-    for (int s = 8; s >= 1; s >>= 1) k += __shfl_xor(k, s, 64);
-    xr = readlane_d(k, 0); xi = readlane_d(k, 16); xe = readlane_d(k, 32); xq = readlane_d(k, 48);
+// maximum of non-negative values over the wavefront, DPP only (no LDS round trips): a max-scan leaves it in lane 63
+__device__ __forceinline__ float wave_max_nonneg(float x) {
+    x = fmaxf(x, dpp_s<0x111, 0xF>(x));
+    x = fmaxf(x, dpp_s<0x112, 0xF>(x));
+    x = fmaxf(x, dpp_s<0x114, 0xF>(x));
+    x = fmaxf(x, dpp_s<0x118, 0xF>(x));
+    x = fmaxf(x, dpp_s<0x142, 0xA>(x));
+    x = fmaxf(x, dpp_s<0x143, 0xC>(x));
+    return readlane_f(x, 63);
 }
 struct ScExact { double pr, pi, num, den; }; // exact sums at the chosen lag; k_sc_post turns them into CFO and metric
 
 // Exact decision among <= 4 candidate lags of one frame (one wavefront; samples in LDS): f64 sums over the window,
-// first maximum wins.  Out of line: it runs once per frame in one wavefront of four.
-__device__ __attribute__((noinline)) void sc_exact_pick(const cf *raw, int c0, int c1, int c2, int c3, int cnt, int L, int W, int lane,
-                                                        int32_t *d_hat, ScExact *ex) {
+// first maximum wins.  All of a candidate's LDS reads are issued together and the four sums are reduced with DPP
+// scans, so a candidate costs one LDS round trip.
+__device__ __forceinline__ void sc_exact_pick(const cf *raw, int c0, int c1, int c2, int c3, int cnt, int L, int W, int lane,
+                                              int32_t *d_hat, ScExact *ex) {
     Cand best = Cand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
     for (int i = 0; i < cnt; ++i) {
         const int d = i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3;
+        cf sa[4], sb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { // W <= 256 in one go (lanes past the window read sample d and are zeroed)
+            const int m = lane + 64 * t < W ? lane + 64 * t : 0;
+            sa[t] = raw[d + m]; sb[t] = raw[d + m + L];
+        }
         double xr = 0, xi = 0, xe = 0, xq = 0;
-        for (int m = lane; m < W; m += 64) {
-            const cf sa = raw[d + m], sb = raw[d + m + L];
-            const double ar = sa.x, ai = sa.y, br = sb.x, bi = sb.y;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool v = lane + 64 * t < W;
+            const double ar = v ? sa[t].x : 0.f, ai = v ? sa[t].y : 0.f, br = v ? sb[t].x : 0.f, bi = v ? sb[t].y : 0.f;
             xr += ar * br + ai * bi;
             xi += ar * bi - ai * br;
             xe += ar * ar + ai * ai;
             xq += br * br + bi * bi;
         }
-        wave_sum4_d(xr, xi, xe, xq, lane);
+        for (int m = lane + 256; m < W; m += 64) {
+            const cf a = raw[d + m], b = raw[d + m + L];
+            const double ar = a.x, ai = a.y, br = b.x, bi = b.y;
+            xr += ar * br + ai * bi;
+            xi += ar * bi - ai * br;
+            xe += ar * ar + ai * ai;
+            xq += br * br + bi * bi;
+        }
+        xr = readlane_d(wave_scan(xr), 63); xi = readlane_d(wave_scan(xi), 63);
+        xe = readlane_d(wave_scan(xe), 63); xq = readlane_d(wave_scan(xq), 63);
         const double xn = xr * xr + xi * xi, xd = xe * xq;
         if (xd > 0.0) { // first maximum wins: strictly greater replaces, ties go to the lower lag
             const double lhs = xn * best.den, rhs = best.num * xd;
@@ -715,27 +722,27 @@ __global__ __launch_bounds__(256) void k_sc_post(const int32_t *d_hat, const ScE
     if (metric) metric[f] = found ? (float)(e.num / e.den) : 0.f;
 }
 
-template <int WG, int OCC>
-__global__ __launch_bounds__(WG, OCC) void k_sc_cf(ScFastParams p) {
-    constexpr int C = 10, NW = WG / 64;
+// NCH chunks per frame (128 / 256), CPT chunks per thread: thread t owns chunks t, t + WG, ... so that every
+// (wavefront, u) pair is a run of 64 consecutive chunks -- a "virtual wavefront" for the scan and the flag masks.
+// Fewer, fatter threads leave fewer wavefronts idle while one of them does the fine pass.
+template <int NCH, int CPT, int OCC>
+__global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
+    constexpr int C = 10, WG = NCH / CPT, NW = WG / 64, VW = NCH / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     const int L = p.L, W = p.W, n = p.n_lags;
     const int nstaged = 2 * p.n16;
     const int ns = (nstaged + C - 1) / C * C;               // whole 10-sample chunks
     cf *raw = reinterpret_cast<cf *>(smem);                 // [ns + L]; entries past the staged samples stay 0
-    float2 *bq = reinterpret_cast<float2 *>(raw + ns + L);  // [WG + 2] exclusive chunk prefix of q ([WG] = total)
-    float *be = reinterpret_cast<float *>(bq + WG + 2);     // [WG + 2] ... of e
-    float *tes = be + WG + 2;                               // [WG] chunk energies
-    float *wtot = tes + WG;                                 // [NW][4] wave totals
-    unsigned long long *flg = reinterpret_cast<unsigned long long *>(wtot + 4 * NW); // [NW] flagged chunks, one bit per thread
+    float2 *bq = reinterpret_cast<float2 *>(raw + ns + L);  // [NCH + 2] exclusive chunk prefix of q ([NCH] = total)
+    float *be = reinterpret_cast<float *>(bq + NCH + 2);    // [NCH + 2] ... of e
+    float *tes = be + NCH + 2;                              // [NCH] chunk energies
+    float *wtot = tes + NCH;                                // [VW][4] virtual-wave totals
+    unsigned long long *flg = reinterpret_cast<unsigned long long *>(wtot + 4 * VW); // [VW] flagged chunks
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cL = L / C, cW = W / C;
     const unsigned raw_lds = lds_addr(raw);
-    const int n0 = tid * C;
-    const bool has_samples = n0 < ns;
-    const bool live = n0 < n; // this thread owns at least one searched lag (implies tid + cW + cL < WG)
     const float thr_c = p.thr_lo * (1.f - SC_EPS);
 
     auto stage = [&](long long fr) { // this wave's 1-KiB pieces of frame fr -> raw
@@ -754,64 +761,85 @@ __global__ __launch_bounds__(WG, OCC) void k_sc_cf(ScFastParams p) {
     int it = blockIdx.x;
 
     for (; f < p.n_frames; f += fstep, ++it) {
+        const long long t0 = p.debug >= 10 ? (long long)__builtin_amdgcn_s_memtime() : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
         lds_barrier();                                   // B0: ... and everyone else's
+        const long long t1 = p.debug >= 10 ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const bool more = f + fstep < p.n_frames;
-        // ---- phase 1 (f32): chunk totals of q and e
-        float tqr = 0.f, tqi = 0.f, te = 0.f;
-        if (has_samples) {
-            const float4 *pa = reinterpret_cast<const float4 *>(raw + n0), *pb = reinterpret_cast<const float4 *>(raw + n0 + L);
+        // ---- phase 1 (f32): chunk totals of q and e, scanned per virtual wavefront
+        float tqr[CPT], tqi[CPT], te[CPT], iqr[CPT], iqi[CPT], ie[CPT];
 #pragma unroll
-            for (int i = 0; i < C / 2; ++i) {
-                const float4 x = pa[i], y = pb[i];
-                tqr += x.x * y.x + x.y * y.y; tqi += x.x * y.y - x.y * y.x; te += x.x * x.x + x.y * x.y;
-                tqr += x.z * y.z + x.w * y.w; tqi += x.z * y.w - x.w * y.z; te += x.z * x.z + x.w * x.w;
+        for (int u = 0; u < CPT; ++u) {
+            const int n0 = (u * WG + tid) * C;
+            tqr[u] = 0.f; tqi[u] = 0.f; te[u] = 0.f;
+            if (n0 < ns) {
+                const float4 *pa = reinterpret_cast<const float4 *>(raw + n0), *pb = reinterpret_cast<const float4 *>(raw + n0 + L);
+#pragma unroll
+                for (int i = 0; i < C / 2; ++i) {
+                    const float4 x = pa[i], y = pb[i];
+                    tqr[u] += x.x * y.x + x.y * y.y; tqi[u] += x.x * y.y - x.y * y.x; te[u] += x.x * x.x + x.y * x.y;
+                    tqr[u] += x.z * y.z + x.w * y.w; tqi[u] += x.z * y.w - x.w * y.z; te[u] += x.z * x.z + x.w * x.w;
+                }
+            }
+            tes[u * WG + tid] = te[u];
+            iqr[u] = wave_scan_f(tqr[u]); iqi[u] = wave_scan_f(tqi[u]); ie[u] = wave_scan_f(te[u]);
+            if (lane == 63) { const int vw = u * NW + wave; wtot[vw * 4 + 0] = iqr[u]; wtot[vw * 4 + 1] = iqi[u]; wtot[vw * 4 + 2] = ie[u]; }
+        }
+        lds_barrier(); // B2: virtual-wave totals visible
+        const long long t2 = p.debug >= 10 ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        float mybqr[CPT], mybqi[CPT], mybe[CPT];
+        {
+            float wq = lane < VW ? wtot[lane * 4 + 0] : 0.f, wi = lane < VW ? wtot[lane * 4 + 1] : 0.f,
+                  we = lane < VW ? wtot[lane * 4 + 2] : 0.f;
+            float sq = wq, si = wi, se = we;
+            sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
+            sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const int vw = u * NW + wave, vt = u * WG + tid;
+                mybqr[u] = (iqr[u] - tqr[u]) + (readlane_f(sq, vw) - readlane_f(wq, vw));
+                mybqi[u] = (iqi[u] - tqi[u]) + (readlane_f(si, vw) - readlane_f(wi, vw));
+                mybe[u] = (ie[u] - te[u]) + (readlane_f(se, vw) - readlane_f(we, vw));
+                bq[vt] = make_float2(mybqr[u], mybqi[u]);
+                be[vt] = mybe[u];
+                if (vt == NCH - 1) { bq[NCH] = make_float2(mybqr[u] + tqr[u], mybqi[u] + tqi[u]); be[NCH] = mybe[u] + te[u]; } // a backward slide may start here
             }
         }
-        tes[tid] = te;
-        const float iqr = wave_scan_f(tqr), iqi = wave_scan_f(tqi), ie = wave_scan_f(te);
-        if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
-        lds_barrier(); // B2: wave totals visible
-        float wq = lane < NW ? wtot[lane * 4 + 0] : 0.f, wi = lane < NW ? wtot[lane * 4 + 1] : 0.f,
-              we = lane < NW ? wtot[lane * 4 + 2] : 0.f;
-        float sq = wq, si = wi, se = we;
-        sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
-        sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
-        const float mybqr = (iqr - tqr) + (readlane_f(sq, wave) - readlane_f(wq, wave));
-        const float mybqi = (iqi - tqi) + (readlane_f(si, wave) - readlane_f(wi, wave));
-        const float mybe = (ie - te) + (readlane_f(se, wave) - readlane_f(we, wave));
-        bq[tid] = make_float2(mybqr, mybqi);
-        be[tid] = mybe;
-        if (tid == WG - 1) { bq[WG] = make_float2(mybqr + tqr, mybqi + tqi); be[WG] = mybe + te; } // a backward slide may start here
         lds_barrier(); // B3: chunk prefixes visible
+        const long long t3 = p.debug >= 10 ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (p.debug == 2) { lds_barrier(); if (more) stage(f + fstep); continue; }
 
-        // ---- coarse pass: can any of this chunk's 10 lags reach the threshold?
-        bool flag = false;
-        if (live) {
-            const float2 b1 = bq[tid + cW];
-            const float Pr = b1.x - mybqr, Pi = b1.y - mybqi;
-            const float eL = tes[tid + cL], eW = tes[tid + cW], eWL = tes[tid + cW + cL];
-            const float btop = be[tid + cW + cL];
-            const float E0 = be[tid + cW] - mybe, R0 = btop - be[tid + cL];
-            const float dlt = (btop + eWL) * 4e-6f;                       // f32 error of a prefix difference
-            const float ub = __builtin_sqrtf(Pr * Pr + Pi * Pi) * 1.000001f + 0.5f * (te + eL + eW + eWL) + 2.f * dlt;
-            const float Elo = E0 - te - dlt, Rlo = R0 - eL - dlt;
-            flag = ub > 0.f && !(Elo > 0.f && Rlo > 0.f && ub * ub < thr_c * Elo * Rlo);
-        }
-        const unsigned long long fm = __ballot(flag);
-        if (lane == 0) flg[wave] = fm;
-        lds_barrier(); // B4: flags visible
-        unsigned long long fmask[NW];
+        // ---- coarse pass: can any of a chunk's 10 lags reach the threshold?
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
+        for (int u = 0; u < CPT; ++u) {
+            const int vt = u * WG + tid;
+            bool flag = false;
+            if (vt * C < n) { // owns at least one searched lag (implies vt + cW + cL < NCH)
+                const float2 b1 = bq[vt + cW];
+                const float Pr = b1.x - mybqr[u], Pi = b1.y - mybqi[u];
+                const float eL = tes[vt + cL], eW = tes[vt + cW], eWL = tes[vt + cW + cL];
+                const float btop = be[vt + cW + cL];
+                const float E0 = be[vt + cW] - mybe[u], R0 = btop - be[vt + cL];
+                const float dlt = (btop + eWL) * 4e-6f;                       // f32 error of a prefix difference
+                const float ub = __builtin_sqrtf(Pr * Pr + Pi * Pi) * 1.000001f + 0.5f * (te[u] + eL + eW + eWL) + 2.f * dlt;
+                const float Elo = E0 - te[u] - dlt, Rlo = R0 - eL - dlt;
+                flag = ub > 0.f && !(Elo > 0.f && Rlo > 0.f && ub * ub < thr_c * Elo * Rlo);
+            }
+            const unsigned long long fm = __ballot(flag);
+            if (lane == 0) flg[u * NW + wave] = fm;
+        }
+        lds_barrier(); // B4: flags visible
+        const long long t4 = p.debug >= 10 ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        unsigned long long fmask[VW];
+#pragma unroll
+        for (int w = 0; w < VW; ++w) {
             const unsigned long long v = flg[w];
             fmask[w] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
                        (unsigned)__builtin_amdgcn_readfirstlane((int)v);
         }
         auto next_flag = [&](int pos) -> int { // first flagged chunk >= pos, or -1 (wave-uniform)
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
+            for (int w = 0; w < VW; ++w) {
                 if (pos >= (w + 1) * 64) continue;
                 unsigned long long mm = fmask[w];
                 if (pos > w * 64) mm &= ~0ull << (pos - w * 64);
@@ -832,9 +860,10 @@ __global__ __launch_bounds__(WG, OCC) void k_sc_cf(ScFastParams p) {
         if (wave == (it & (NW - 1))) {
             const int hh = lane & 1;
             const float sgn = hh ? -1.f : 1.f;
+            long long u0 = p.debug >= 15 ? (long long)__builtin_amdgcn_s_memtime() : 0, u1 = 0, u2 = 0;
             for (;;) {
                 const int c = gs + (lane >> 1), m0 = c * C;
-                const bool lv = m0 + 5 * hh < n; // implies c + hh + cW + cL < WG
+                const bool lv = m0 + 5 * hh < n; // implies c + hh + cW + cL <= NCH
                 float mp[5];                      // metric of round k: lag m0 + k (forward) or m0 + 9 - k (backward)
                 bool unsafe_t = false;
                 int lo = INT_MAX, hi = INT_MAX;
@@ -842,17 +871,22 @@ __global__ __launch_bounds__(WG, OCC) void k_sc_cf(ScFastParams p) {
                 for (int k = 0; k < 5; ++k) mp[k] = -1.f;
                 if (lv) {
                     const int cb = c + hh;
+                    // every LDS read of the slide up front: one round trip
                     const float2 q0 = bq[cb], q1 = bq[cb + cW];
+                    const float e0 = be[cb], e1 = be[cb + cW], e2 = be[cb + cL], etop = be[cb + cW + cL];
+                    cf sa[5], sb[5], sc[5], sd[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) { // low sample x of the step to round k's lag (forward k = 0 sits on the boundary: no step)
+                        const int x = hh ? m0 + 9 - k : m0 + (k > 0 ? k - 1 : 0);
+                        sa[k] = raw[x]; sb[k] = raw[x + L]; sc[k] = raw[x + W]; sd[k] = raw[x + W + L];
+                    }
                     float Pr = q1.x - q0.x, Pi = q1.y - q0.y;
-                    const float etop = be[cb + cW + cL];
-                    float E = be[cb + cW] - be[cb], R = etop - be[cb + cL];
+                    float E = e1 - e0, R = etop - e2;
                     float emin = 3.0e38f, mmax = -1.f;
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {
-                        // update to this round's lag: low sample x of the step (forward k = 0 sits on the boundary: no step)
-                        const int x = hh ? m0 + 9 - k : m0 + (k > 0 ? k - 1 : 0);
                         const float w = (hh || k > 0) ? sgn : 0.f;
-                        const cf a = raw[x], b = raw[x + L], cc = raw[x + W], d = raw[x + W + L];
+                        const cf a = sa[k], b = sb[k], cc = sc[k], d = sd[k];
                         Pr += w * (cc.x * d.x + cc.y * d.y - a.x * b.x - a.y * b.y);
                         Pi += w * (cc.x * d.y - cc.y * d.x - a.x * b.y + a.y * b.x);
                         E += w * (cc.x * cc.x + cc.y * cc.y - a.x * a.x - a.y * a.y);
@@ -877,6 +911,7 @@ __global__ __launch_bounds__(WG, OCC) void k_sc_cf(ScFastParams p) {
                     }
                 }
                 if (p.debug == 5) break;
+                if (p.debug >= 15) u1 = (long long)__builtin_amdgcn_s_memtime();
                 const unsigned long long lo_m = __ballot(lo != INT_MAX), hi_m = __ballot(hi != INT_MAX);
                 if (lo_m == 0) { // nothing crosses in these 32 chunks: on to the next flagged chunk
                     gs = next_flag(gs + 32);
@@ -898,7 +933,7 @@ __global__ __launch_bounds__(WG, OCC) void k_sc_cf(ScFastParams p) {
                     inw[k] = lag >= d1 && lag <= dend && mp[k] >= 0.f;
                     if (inw[k] && !unsafe_t) lmax = fmaxf(lmax, mp[k]);
                 }
-                const float mcut = wave_max_f(lmax) * (1.f - 2.f * SC_EPS);
+                const float mcut = wave_max_nonneg(lmax) * (1.f - 2.f * SC_EPS);
                 unsigned cm = 0; // this lane's candidate rounds
 #pragma unroll
                 for (int k = 0; k < 5; ++k) cm |= (inw[k] && (unsafe_t || mp[k] >= mcut)) ? 1u << k : 0u;
@@ -919,18 +954,28 @@ __global__ __launch_bounds__(WG, OCC) void k_sc_cf(ScFastParams p) {
                 if (cnt == 0) { if (lane == 0) p.d_hat[f] = -1; break; }
                 if (cnt > SC_MAXCAND) { if (lane == 0) to_slow(f); break; }
                 if (p.debug == 4) break;
+                if (p.debug >= 15) u2 = (long long)__builtin_amdgcn_s_memtime();
                 sc_exact_pick(raw, cand[0], cand[1], cand[2], cand[3], cnt, L, W, lane, p.d_hat + f, p.exact + f);
+                if (p.debug >= 15 && lane == 0) { // profiling aid: slide / select / exact time of the fine wavefront
+                    const long long u3 = (long long)__builtin_amdgcn_s_memtime();
+                    p.d_hat[f] = (int32_t)(p.debug == 15 ? u1 - u0 : p.debug == 16 ? u2 - u1 : u3 - u2);
+                }
                 break;
             }
         }
         lds_barrier(); // B5: the fine wavefront is done with the raw samples
+        if (p.debug >= 10 && p.debug < 15 && tid == 0) { // profiling aid: per-frame section time (s_memtime ticks) instead of the timing result
+            const long long t5 = (long long)__builtin_amdgcn_s_memtime();
+            const long long dt[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4};
+            p.d_hat[f] = (int32_t)dt[p.debug - 10 < 5 ? p.debug - 10 : 4];
+        }
         if (more) stage(f + fstep);
     }
 }
-static size_t sc_cf_lds_bytes(int L, int wg, long long frame_len) { // raw samples + chunk prefixes, energies, flags
+static size_t sc_cf_lds_bytes(int L, int nch, long long frame_len) { // raw samples + chunk prefixes, energies, flags
     long long ns = ((frame_len + 1) / 2 * 2 + 9) / 10 * 10;
-    if (ns > (long long)wg * 10) ns = (long long)wg * 10;
-    return (size_t)(ns + L) * sizeof(float2) + (size_t)(wg + 2) * (sizeof(float2) + sizeof(float)) + (size_t)wg * sizeof(float) +
+    if (ns > (long long)nch * 10) ns = (long long)nch * 10;
+    return (size_t)(ns + L) * sizeof(float2) + (size_t)(nch + 2) * (sizeof(float2) + sizeof(float)) + (size_t)nch * sizeof(float) +
            16 * sizeof(float) + 64 + 16;
 }
 
@@ -1062,7 +1107,7 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     long long grid = (long long)num_cu * per_cu;
     if (grid > p.n_frames) grid = p.n_frames;
     static const int slide = [] { const char *e = getenv("OFDM_SC_SLIDE"); return e ? atoi(e) : 0; }(); // A/B knob: workgroups per CU
-    static const int cfk = [] { const char *e = getenv("OFDM_SC_CF"); return e ? atoi(e) : 5; }(); // workgroups per CU; 0 = previous generation
+    static const int cfk = [] { const char *e = getenv("OFDM_SC_CF"); return e ? atoi(e) : 7; }(); // workgroups per CU; 0 = previous generation
     if (cfk > 0 && p.W + 2 * 10 <= 320) { // the fine pass looks at 320 lags from the first flagged chunk
         ScExact *exact = reinterpret_cast<ScExact *>(workspace); // aliases rec / mwin of the previous generation
         q.exact = exact;
@@ -1075,11 +1120,16 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         if (pc > cfk) pc = cfk;
         grid = (long long)num_cu * pc;
         if (grid > p.n_frames) grid = p.n_frames;
+        static const int cpt = [] { const char *e = getenv("OFDM_SC_CPT"); return e ? atoi(e) : 2; }(); // A/B knob: chunks per thread
         if (wg == 256) {
-            if (cfk >= 6) hipLaunchKernelGGL((k_sc_cf<256, 6>), dim3((unsigned)grid), dim3(256), l4, st, q);
-            else if (cfk == 5) hipLaunchKernelGGL((k_sc_cf<256, 5>), dim3((unsigned)grid), dim3(256), l4, st, q);
-            else hipLaunchKernelGGL((k_sc_cf<256, 4>), dim3((unsigned)grid), dim3(256), l4, st, q);
-        } else hipLaunchKernelGGL((k_sc_cf<128, 5>), dim3((unsigned)grid), dim3(128), l4, st, q);
+            if (cpt == 2) {
+                hipLaunchKernelGGL((k_sc_cf<256, 2, 4>), dim3((unsigned)grid), dim3(128), l4, st, q); // <= 7 x 2 waves per CU
+            } else if (cpt == 4) hipLaunchKernelGGL((k_sc_cf<256, 4, 2>), dim3((unsigned)grid), dim3(64), l4, st, q);
+            else if (cfk >= 6) hipLaunchKernelGGL((k_sc_cf<256, 1, 6>), dim3((unsigned)grid), dim3(256), l4, st, q);
+            else if (cfk == 5) hipLaunchKernelGGL((k_sc_cf<256, 1, 5>), dim3((unsigned)grid), dim3(256), l4, st, q);
+            else hipLaunchKernelGGL((k_sc_cf<256, 1, 4>), dim3((unsigned)grid), dim3(256), l4, st, q);
+        } else if (cpt >= 2) hipLaunchKernelGGL((k_sc_cf<128, 2, 2>), dim3((unsigned)grid), dim3(64), l4, st, q);
+        else hipLaunchKernelGGL((k_sc_cf<128, 1, 5>), dim3((unsigned)grid), dim3(128), l4, st, q);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(k_sc_post, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, p.d_hat, exact, p.n_frames, p.L,
                            p.f_delta, p.metric);

@@ -1,0 +1,20 @@
+"""Profiling aid: per-section time of the Schmidl-Cox filter kernel (s_memtime ticks per frame, median over frames)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ofdm_amd import api
+from tools import bench_cfg3
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
+x, _ = bench_cfg3.synth(api, torch, ctx, n, 2176)
+names = ["dma_wait", "phase1", "bases", "coarse", "fine", "fine.slide", "fine.select", "fine.exact"]
+for k, nm in enumerate(names):
+    os.environ["OFDM_SC_DEBUG"] = str(10 + k)
+    dh, _, _ = ctx.sc_correlate(x)
+    torch.cuda.synchronize()
+    d = dh.to(torch.float64)
+    print(nm, "median", float(d.median()), "mean", float(d.mean()), "p90", float(d.quantile(0.9)))
+os.environ["OFDM_SC_DEBUG"] = "0"
+ctx.timer_start()
+for _ in range(5): ctx.sc_correlate(x)
+print("ms per", n, "frames:", ctx.timer_stop_ms() / 5)
