@@ -20,7 +20,7 @@ HEADERS = ["device_common.hpp", "kernels.hpp", os.path.join("..", "..", "include
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # per-file additions.  kernels_sync: the SLP vectoriser pairs f32 ops into v_pk_* and pays for it in v_mov (measured:
 # 332 -> 246 VALU in the filter's phase 1, 16 fewer VGPRs)
-EXTRA_FLAGS = {"kernels_sync.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"kernels_sync.hip": ["-fno-slp-vectorize"], "kernels_fast.hip": ["-fno-slp-vectorize"], "kernels_sym.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

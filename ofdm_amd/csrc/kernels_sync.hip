@@ -215,12 +215,13 @@ int sc_tile_lags() { return SC_CH; }
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Fast Schmidl-Cox path for one-tile frames with a short period (N <= 256) and 16-byte aligned frame bases:
-// "filter in f32, decide in f64".
-//   * every product q[n] = conj(r[n]) r[n+L] and energy e[n] = |r[n]|^2 is formed ONCE, in f32; each thread owns a run
-//     of consecutive samples and writes its exclusive local prefix sums to LDS; a DPP wavefront scan (row shifts /
-//     broadcasts) plus the wave totals give every chunk's base;
-//   * a lag is four prefix differences:  P(d) = C_q[d+W] - C_q[d],  E(d) = C_e[d+W] - C_e[d],  R(d) = E(d+L);
+// Fast Schmidl-Cox path for one-tile frames with a short period (L = 80: N = 64) and 16-byte aligned frame bases:
+// "filter in f32, decide in f64", and only look closely where a packet can be.
+//   * every product q[n] = conj(r[n]) r[n+L] and energy e[n] = |r[n]|^2 is formed ONCE, in f32, and summed over
+//     10-sample chunks; a DPP wavefront scan (row shifts / broadcasts) plus the wave totals give exclusive chunk
+//     prefixes, so the sums at a chunk's first lag are prefix differences:
+//         P = Bq[c + W/10] - Bq[c],   E = Be[c + W/10] - Be[c],   R = Be[c + (W+L)/10] - Be[c + L/10];
+//   * a bound on the metric over each chunk's 10 lags discards the chunks that cannot reach the threshold (k_sc_cf);
 //   * decisions are EXACT: the f32 metric (absolute error <= ~5e-6 x prefix-energy / window-energy) only filters.
 //     The first crossing is accepted from f32 when "M >= thr(1-EPS)" and "M >= thr(1+EPS)" first hold at the same lag;
 //     the peak is re-evaluated in f64 (products of f32 are exact in f64) at every lag within 2 EPS of the f32 window
@@ -282,360 +283,23 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char *)p);
 }
 
-// what the filter kernel hands to the finish kernel: the first crossing d1 and the f32 metric of the nwin lags of
-// [d1, d1 + W] (in mwin; +inf marks a lag the filter does not trust, -1 a lag without energy)
-struct ScRec { int32_t state; int32_t d1; int32_t nwin; int32_t pad; }; // state: -1 no packet, -2 slow list, 1 window stored
-
 struct ScFastParams {
     const float2 *in;
     long long n_frames, frame_stride;
-    int n16;        // 16-byte pieces to stage per frame = min(SP_N, frame_len) / 2
+    int n16;        // 16-byte pieces to stage per frame = min(10 NCH, frame_len) / 2
     int n_lags, L, W;
-    int debug;      // profiling aid (OFDM_SC_DEBUG): 1 = no staging after the first tile, 2 = stop after phase 1, 3 = after packet detect
+    int debug;      // profiling aid (OFDM_SC_DEBUG): 2 / 3 / 5 / 4 stop after phase 1 / coarse / slide / select; 10..17 section times
     float thr_lo, thr_hi;
-    double thr;
     int32_t *d_hat;
-    ScRec *rec;
-    float *mwin;    // [n_frames][wstride] f32 metric over the peak window
-    int wstride;
     int32_t *slow_list; // frames the filter could not settle
     int32_t *slow_count;
-    struct ScExact *exact; // k_sc_cf: exact sums at the chosen lag, per frame
+    struct ScExact *exact; // exact sums at the chosen lag, per frame
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_sc_fast2: second-generation fast path (same "filter in f32, decide in f64" contract as k_sc_fast), shaped by
-// the counters of round 1 (a VALU op costs ~4 SIMD cycles; k_sc_fast waves were parked 52 % of the time):
-//   * 10 samples / lags per thread (256-thread workgroup per 2560-sample tile): per-thread overhead (scan, bases,
-//     candidate bookkeeping) is amortised over twice the samples and every LDS access is a 16- or 8-byte op;
-//   * the f32 prefix array of q ALIASES the raw tile (raw -> registers -> barrier -> prefixes), so a workgroup needs
-//     35 KB of LDS and FOUR independent workgroups share a CU: one group's barrier / DMA stalls hide behind the others;
-//   * the next frame's LDS-DMA is issued as soon as the prefixes are dead (after the packet-detect barrier);
-//   * the few exact f64 re-evaluations read their 2 x 240 samples back from global memory (L2 hits).
-__device__ __forceinline__ bool more_dbg(const ScFastParams &p, long long f, long long fstep) { return f + fstep < p.n_frames; }
-template <int WG>
-__global__ __launch_bounds__(WG, 3) void k_sc_fast2(ScFastParams p) {
-    constexpr int C = 10, TN = WG * C, NW = WG / 64;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int L = p.L, W = p.W, n = p.n_lags;
-    // arrays are sized to the staged samples (ns = 2 * n16 <= TN), not to the tile: a 2176-sample frame needs 47 KB
-    const int ns = (2 * p.n16 + C - 1) / C * C; // whole 10-sample chunks
-    cf *raw = reinterpret_cast<cf *>(smem);                 // [ns + L] raw samples (entries past ns are never used by a valid lag)
-    float2 *lq = reinterpret_cast<float2 *>(raw + ns + L);  // [ns] exclusive local prefix of q
-    float *le = reinterpret_cast<float *>(lq + ns);         // [ns] exclusive local prefix of e
-    float2 *bq = reinterpret_cast<float2 *>(le + ns);       // [WG] chunk bases
-    float *be = reinterpret_cast<float *>(bq + WG);         // [WG]
-    float *wtot = be + WG;                                  // [NW][4] wave totals
-    int *sh = reinterpret_cast<int *>(wtot + 4 * NW);       // [2][8] per-parity: lo, hi, max bits, count, cand[4]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cL = L / C, cW = W / C;
-    const unsigned raw_lds = lds_addr(raw);
-    const int n0 = tid * C;
-    const bool has_samples = n0 < 2 * p.n16;
-    const bool live = n0 < n; // this thread owns at least one searched lag (implies tid + cW + cL < WG)
-
-    auto stage = [&](long long fr) { // this wave's 1-KiB pieces of frame fr -> raw tile
-        const char *sbase = reinterpret_cast<const char *>(p.in + fr * p.frame_stride);
-        for (int piece = wave; piece * 64 < p.n16; piece += NW) {
-            const int i = piece * 64 + lane;
-            if (i < p.n16) glds16(sbase, (unsigned)i * 16u, raw_lds + (unsigned)piece * 1024u);
-        }
-    };
-    long long f = blockIdx.x;
-    const long long fstep = gridDim.x;
-    if (f < p.n_frames) stage(f);
-    if (tid < 16) sh[tid] = (tid & 7) < 2 ? INT_MAX : 0;
-    int cur = 0;
-
-    for (; f < p.n_frames; f += fstep, cur ^= 1) {
-        int *S = sh + cur * 8;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
-        lds_barrier();                                   // B0: ... and everyone else's
-        const bool more = f + fstep < p.n_frames;
-        if (tid < 8) sh[(cur ^ 1) * 8 + tid] = tid < 2 ? INT_MAX : 0;
-        // ---- phase 1 (f32): products once per sample (16-byte LDS reads), exclusive local prefixes to LDS
-        float rqr = 0.f, rqi = 0.f, re = 0.f;
-        if (has_samples) {
-            const float4 *pa = reinterpret_cast<const float4 *>(raw + n0), *pb = reinterpret_cast<const float4 *>(raw + n0 + L);
-            cf a[C], b[C];
-#pragma unroll
-            for (int i = 0; i < C / 2; ++i) {
-                const float4 x = pa[i], y = pb[i];
-                a[2 * i] = make_float2(x.x, x.y); a[2 * i + 1] = make_float2(x.z, x.w);
-                b[2 * i] = make_float2(y.x, y.y); b[2 * i + 1] = make_float2(y.z, y.w);
-            }
-            float4 *wq4 = reinterpret_cast<float4 *>(lq + n0);
-            float2 *we2 = reinterpret_cast<float2 *>(le + n0);
-#pragma unroll
-            for (int i = 0; i < C / 2; ++i) { // two samples per step: one 16-byte and one 8-byte LDS store
-                const int j = 2 * i;
-                const float q0r = rqr, q0i = rqi, e0 = re;
-                rqr += a[j].x * b[j].x + a[j].y * b[j].y;
-                rqi += a[j].x * b[j].y - a[j].y * b[j].x;
-                re += a[j].x * a[j].x + a[j].y * a[j].y;
-                wq4[i] = make_float4(q0r, q0i, rqr, rqi);
-                we2[i] = make_float2(e0, re);
-                rqr += a[j + 1].x * b[j + 1].x + a[j + 1].y * b[j + 1].y;
-                rqi += a[j + 1].x * b[j + 1].y - a[j + 1].y * b[j + 1].x;
-                re += a[j + 1].x * a[j + 1].x + a[j + 1].y * a[j + 1].y;
-            }
-        }
-        const float iqr = wave_scan_f(rqr), iqi = wave_scan_f(rqi), ie = wave_scan_f(re);
-        if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
-        lds_barrier(); // B2: wave totals visible; every thread is done with the raw samples
-        if (more && p.debug != 1 && p.debug != 4) stage(f + fstep); // next frame's LDS-DMA flies behind the bases, phase 2A and the tail
-        float wq = lane < NW ? wtot[lane * 4 + 0] : 0.f, wi = lane < NW ? wtot[lane * 4 + 1] : 0.f,
-              we = lane < NW ? wtot[lane * 4 + 2] : 0.f;
-        float sq = wq, si = wi, se = we;
-        sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
-        sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
-        const float mybqr = (iqr - rqr) + (readlane_f(sq, wave) - readlane_f(wq, wave));
-        const float mybqi = (iqi - rqi) + (readlane_f(si, wave) - readlane_f(wi, wave));
-        const float mybe = (ie - re) + (readlane_f(se, wave) - readlane_f(we, wave));
-        bq[tid] = make_float2(mybqr, mybqi);
-        be[tid] = mybe;
-        lds_barrier(); // B3
-        if (p.debug == 2) continue;
-
-        // ---- phase 2A (f32): metric at this thread's 10 lags, two lags per packed op
-        float2 mp[C / 2];     // f32 metric of lags (2i, 2i+1); -1 where the lag is not searched / has no energy
-        bool unsafe_t = false; // this thread's lags are not trusted (prefix energy >> window energy): decided exactly
-#pragma unroll
-        for (int i = 0; i < C / 2; ++i) mp[i] = make_float2(-1.f, -1.f);
-        if (live) {
-            const float2 b1 = bq[tid + cW];
-            const float dBqr = b1.x - mybqr, dBqi = b1.y - mybqi;
-            const float etop = be[tid + cW + cL];
-            const float dBe = be[tid + cW] - mybe, dBr = etop - be[tid + cL];
-            const float4 *pq = reinterpret_cast<const float4 *>(lq + n0 + W), *pq0 = reinterpret_cast<const float4 *>(lq + n0);
-            const float2 *p1 = reinterpret_cast<const float2 *>(le + n0 + W), *p2 = reinterpret_cast<const float2 *>(le + n0 + W + L),
-                         *p3 = reinterpret_cast<const float2 *>(le + n0 + L), *p0 = reinterpret_cast<const float2 *>(le + n0);
-            float emin = 3.0e38f, mmax = -1.f;
-#pragma unroll
-            for (int i = 0; i < C / 2; ++i) {
-                const float4 q4 = pq[i], o4 = pq0[i];
-                const float2 x1 = p1[i], x2 = p2[i], x3 = p3[i], x0 = p0[i];
-                const float2 E = make_float2((x1.x - x0.x) + dBe, (x1.y - x0.y) + dBe);
-                const float2 R = make_float2((x2.x - x3.x) + dBr, (x2.y - x3.y) + dBr);
-                const float2 den = make_float2(E.x * R.x, E.y * R.y);
-                const float ar = (q4.x - o4.x) + dBqr, ai = (q4.y - o4.y) + dBqi, br = (q4.z - o4.z) + dBqr, bi = (q4.w - o4.w) + dBqi;
-                const float2 num = make_float2(ar * ar + ai * ai, br * br + bi * bi);
-                const bool ok0 = den.x > 0.f && n0 + 2 * i < n, ok1 = den.y > 0.f && n0 + 2 * i + 1 < n;
-                mp[i].x = ok0 ? num.x * __builtin_amdgcn_rcpf(den.x) : -1.f;
-                mp[i].y = ok1 ? num.y * __builtin_amdgcn_rcpf(den.y) : -1.f;
-                emin = fminf(emin, fminf(ok0 ? fminf(E.x, R.x) : 3.0e38f, ok1 ? fminf(E.y, R.y) : 3.0e38f));
-                mmax = fmaxf(mmax, fmaxf(mp[i].x, mp[i].y));
-            }
-            unsafe_t = etop > SC_UNSAFE_RATIO * emin; // emin stays huge when no lag has energy
-            if (unsafe_t || mmax >= p.thr_lo) {        // only threads near the packet scan their lags for the crossing
-                int lo = INT_MAX, hi = INT_MAX;
-#pragma unroll
-                for (int j = C - 1; j >= 0; --j) {
-                    const float m = (j & 1) ? mp[j >> 1].y : mp[j >> 1].x;
-                    if (m >= 0.f && (unsafe_t || m >= p.thr_lo)) lo = n0 + j;
-                    if (m >= 0.f && !unsafe_t && m >= p.thr_hi) hi = n0 + j;
-                }
-                if (lo != INT_MAX) atomicMin(&S[0], lo);
-                if (hi != INT_MAX) atomicMin(&S[1], hi);
-            }
-        }
-        lds_barrier(); // B4
-        if (more && p.debug == 4) stage(f + fstep);
-        const int c_lo = S[0], c_hi = S[1];
-        if (p.debug == 3) continue;
-        if (c_lo == INT_MAX || c_lo != c_hi) {
-            if (tid == 0) {
-                p.d_hat[f] = -1;
-                if (c_lo == INT_MAX) p.rec[f] = ScRec{-1, 0, 0, 0}; // nothing reaches the threshold: no packet
-                else { p.rec[f] = ScRec{-2, 0, 0, 0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; } // ambiguous crossing: redo in f64
-            }
-            continue;
-        }
-        const int d1 = c_lo;
-        // ---- hand the peak window to the finish kernel: f32 metric of every lag of [d1, d1 + W] (exact compare there)
-        if (live && n0 + C > d1 && n0 <= d1 + W) {
-            float *mw = p.mwin + f * p.wstride;
-#pragma unroll
-            for (int j = 0; j < C; ++j) {
-                const int d = n0 + j;
-                const float m = (j & 1) ? mp[j >> 1].y : mp[j >> 1].x;
-                if (d >= d1 && d <= d1 + W && d < n) mw[d - d1] = (unsafe_t && m >= 0.f) ? __builtin_inff() : m;
-            }
-        }
-        if (tid == 0) {
-            const int nw = n - d1 < W + 1 ? n - d1 : W + 1;
-            p.rec[f] = ScRec{1, d1, nw, 0};
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_sc_slide: third generation of the filter.  Same contract (f32 filter, exact f64 decisions in k_sc_finish), but NO
-// per-sample prefix arrays: LDS holds only the raw samples (18 KB for a 2176-sample frame) and a per-chunk prefix
-// (3 KB), so six workgroups share a CU instead of three.
-//   phase 1: thread t sums q = conj(r[n]) r[n+L] and e = |r[n]|^2 over its 10 samples; one workgroup scan turns the
-//            chunk totals into exclusive chunk prefixes Bq / Be;
-//   phase 2: P, E, R at the thread's first lag are chunk-prefix differences; the other 9 lags SLIDE the window:
-//            P += q[d+W] - q[d], E += e[d+W] - e[d], R += e[d+W+L] - e[d+L], products recomputed from the raw samples
-//            (4 x 80 B of LDS reads per thread instead of 120 B of prefix stores + 320 B of prefix reads).
-template <int WG, int OCC>
-__global__ __launch_bounds__(WG, OCC) void k_sc_slide(ScFastParams p) {
-    constexpr int C = 10, NW = WG / 64;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int L = p.L, W = p.W, n = p.n_lags;
-    const int nstaged = 2 * p.n16;
-    const int ns = (nstaged + C - 1) / C * C;               // whole 10-sample chunks
-    cf *raw = reinterpret_cast<cf *>(smem);                 // [ns + L]; entries past the staged samples stay 0
-    float2 *bq = reinterpret_cast<float2 *>(raw + ns + L);  // [WG] exclusive chunk prefix of q
-    float *be = reinterpret_cast<float *>(bq + WG);         // [WG] ... of e
-    float *wtot = be + WG;                                  // [NW][4] wave totals
-    int *sh = reinterpret_cast<int *>(wtot + 4 * NW);       // [2][8] per-parity: lo, hi
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cL = L / C, cW = W / C;
-    const unsigned raw_lds = lds_addr(raw);
-    const int n0 = tid * C;
-    const bool has_samples = n0 < ns;
-    const bool live = n0 < n; // this thread owns at least one searched lag (implies tid + cW + cL < WG)
-
-    auto stage = [&](long long fr) { // this wave's 1-KiB pieces of frame fr -> raw
-        const char *sbase = reinterpret_cast<const char *>(p.in + fr * p.frame_stride);
-        for (int piece = wave; piece * 64 < p.n16; piece += NW) {
-            const int i = piece * 64 + lane;
-            if (i < p.n16) glds16(sbase, (unsigned)i * 16u, raw_lds + (unsigned)piece * 1024u);
-        }
-    };
-    for (int i = nstaged + tid; i < ns + L; i += WG) raw[i] = make_float2(0.f, 0.f); // never written by the DMA
-    long long f = blockIdx.x;
-    const long long fstep = gridDim.x;
-    if (f < p.n_frames) stage(f);
-    if (tid < 16) sh[tid] = (tid & 7) < 2 ? INT_MAX : 0;
-    int cur = 0;
-
-    for (; f < p.n_frames; f += fstep, cur ^= 1) {
-        int *S = sh + cur * 8;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
-        lds_barrier();                                   // B0: ... and everyone else's
-        const bool more = f + fstep < p.n_frames;
-        if (tid < 8) sh[(cur ^ 1) * 8 + tid] = tid < 2 ? INT_MAX : 0;
-        // ---- phase 1 (f32): chunk totals of q and e
-        float tqr = 0.f, tqi = 0.f, te = 0.f;
-        const float4 *pa = reinterpret_cast<const float4 *>(raw + n0), *pb = reinterpret_cast<const float4 *>(raw + n0 + L);
-        if (has_samples) {
-#pragma unroll
-            for (int i = 0; i < C / 2; ++i) {
-                const float4 x = pa[i], y = pb[i];
-                tqr += x.x * y.x + x.y * y.y; tqi += x.x * y.y - x.y * y.x; te += x.x * x.x + x.y * x.y;
-                tqr += x.z * y.z + x.w * y.w; tqi += x.z * y.w - x.w * y.z; te += x.z * x.z + x.w * x.w;
-            }
-        }
-        const float iqr = wave_scan_f(tqr), iqi = wave_scan_f(tqi), ie = wave_scan_f(te);
-        if (lane == 63) { wtot[wave * 4 + 0] = iqr; wtot[wave * 4 + 1] = iqi; wtot[wave * 4 + 2] = ie; }
-        lds_barrier(); // B2: wave totals visible
-        float wq = lane < NW ? wtot[lane * 4 + 0] : 0.f, wi = lane < NW ? wtot[lane * 4 + 1] : 0.f,
-              we = lane < NW ? wtot[lane * 4 + 2] : 0.f;
-        float sq = wq, si = wi, se = we;
-        sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
-        sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
-        const float mybqr = (iqr - tqr) + (readlane_f(sq, wave) - readlane_f(wq, wave));
-        const float mybqi = (iqi - tqi) + (readlane_f(si, wave) - readlane_f(wi, wave));
-        const float mybe = (ie - te) + (readlane_f(se, wave) - readlane_f(we, wave));
-        bq[tid] = make_float2(mybqr, mybqi);
-        be[tid] = mybe;
-        lds_barrier(); // B3: chunk prefixes visible
-        if (p.debug == 2) { lds_barrier(); if (more) stage(f + fstep); continue; }
-
-        // ---- phase 2 (f32): metric at this thread's 10 lags by sliding the window
-        float mp[C];           // f32 metric; -1 where the lag is not searched / has no energy
-        bool unsafe_t = false; // this thread's lags are not trusted (prefix energy >> window energy): decided exactly
-#pragma unroll
-        for (int j = 0; j < C; ++j) mp[j] = -1.f;
-        if (live) {
-            const float2 b1 = bq[tid + cW];
-            float Pr = b1.x - mybqr, Pi = b1.y - mybqi;
-            const float etop = be[tid + cW + cL];
-            float E = be[tid + cW] - mybe, R = etop - be[tid + cL];
-            const float4 *pc = reinterpret_cast<const float4 *>(raw + n0 + W), *pd = reinterpret_cast<const float4 *>(raw + n0 + W + L);
-            float emin = 3.0e38f, mmax = -1.f;
-#pragma unroll
-            for (int i = 0; i < C / 2; ++i) {
-                const float4 a = pa[i], b = pb[i], c = pc[i], d = pd[i];
-                {
-                    const float den = E * R;
-                    const bool ok = den > 0.f && n0 + 2 * i < n;
-                    mp[2 * i] = ok ? (Pr * Pr + Pi * Pi) * __builtin_amdgcn_rcpf(den) : -1.f;
-                    emin = fminf(emin, ok ? fminf(E, R) : 3.0e38f);
-                    mmax = fmaxf(mmax, mp[2 * i]);
-                    Pr += c.x * d.x + c.y * d.y - a.x * b.x - a.y * b.y;
-                    Pi += c.x * d.y - c.y * d.x - a.x * b.y + a.y * b.x;
-                    E += c.x * c.x + c.y * c.y - a.x * a.x - a.y * a.y;
-                    R += d.x * d.x + d.y * d.y - b.x * b.x - b.y * b.y;
-                }
-                {
-                    const float den = E * R;
-                    const bool ok = den > 0.f && n0 + 2 * i + 1 < n;
-                    mp[2 * i + 1] = ok ? (Pr * Pr + Pi * Pi) * __builtin_amdgcn_rcpf(den) : -1.f;
-                    emin = fminf(emin, ok ? fminf(E, R) : 3.0e38f);
-                    mmax = fmaxf(mmax, mp[2 * i + 1]);
-                    Pr += c.z * d.z + c.w * d.w - a.z * b.z - a.w * b.w;
-                    Pi += c.z * d.w - c.w * d.z - a.z * b.w + a.w * b.z;
-                    E += c.z * c.z + c.w * c.w - a.z * a.z - a.w * a.w;
-                    R += d.z * d.z + d.w * d.w - b.z * b.z - b.w * b.w;
-                }
-            }
-            unsafe_t = etop > SC_UNSAFE_RATIO * emin; // emin stays huge when no lag has energy
-            if (unsafe_t || mmax >= p.thr_lo) {        // only threads near the packet scan their lags for the crossing
-                int lo = INT_MAX, hi = INT_MAX;
-#pragma unroll
-                for (int j = C - 1; j >= 0; --j) {
-                    const float m = mp[j];
-                    if (m >= 0.f && (unsafe_t || m >= p.thr_lo)) lo = n0 + j;
-                    if (m >= 0.f && !unsafe_t && m >= p.thr_hi) hi = n0 + j;
-                }
-                if (lo != INT_MAX) atomicMin(&S[0], lo);
-                if (hi != INT_MAX) atomicMin(&S[1], hi);
-            }
-        }
-        lds_barrier(); // B4: crossing known; the raw samples are dead
-        if (more) stage(f + fstep);
-        const int c_lo = S[0], c_hi = S[1];
-        if (p.debug == 3) continue;
-        if (c_lo == INT_MAX || c_lo != c_hi) {
-            if (tid == 0) {
-                p.d_hat[f] = -1;
-                if (c_lo == INT_MAX) p.rec[f] = ScRec{-1, 0, 0, 0}; // nothing reaches the threshold: no packet
-                else { p.rec[f] = ScRec{-2, 0, 0, 0}; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)f; } // ambiguous crossing: redo in f64
-            }
-            continue;
-        }
-        const int d1 = c_lo;
-        // ---- hand the peak window to the finish kernel: f32 metric of every lag of [d1, d1 + W] (exact compare there)
-        if (live && n0 + C > d1 && n0 <= d1 + W) {
-            float *mw = p.mwin + f * p.wstride;
-#pragma unroll
-            for (int j = 0; j < C; ++j) {
-                const int d = n0 + j;
-                if (d >= d1 && d <= d1 + W && d < n) mw[d - d1] = (unsafe_t && mp[j] >= 0.f) ? __builtin_inff() : mp[j];
-            }
-        }
-        if (tid == 0) {
-            const int nw = n - d1 < W + 1 ? n - d1 : W + 1;
-            p.rec[f] = ScRec{1, d1, nw, 0};
-        }
-    }
-}
-static size_t sc_slide_lds_bytes(int L, int wg, long long frame_len) { // raw samples + chunk prefixes
-    long long ns = ((frame_len + 1) / 2 * 2 + 9) / 10 * 10;
-    if (ns > (long long)wg * 10) ns = (long long)wg * 10;
-    return (size_t)(ns + L) * sizeof(float2) + (size_t)wg * (sizeof(float2) + sizeof(float)) + 16 * sizeof(float) + 16 * sizeof(int) + 16;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_sc_cf: coarse-then-fine filter (fourth generation).  The per-lag metric is only ever needed around the packet:
-// at the first threshold crossing and over the W + 1 lags after it.  So
+// k_sc_cf: coarse-then-fine filter.  The per-lag metric is only ever needed around the packet: at the first threshold
+// crossing and over the W + 1 lags after it.  One workgroup per frame (persistent over the frame list), the frame
+// staged once from HBM into LDS by LDS-DMA (global_load_lds_dwordx4), then
 //   phase 1  (all threads)  chunk totals of q = conj(r[n]) r[n+L] and e = |r[n]|^2 over 10-sample chunks, one
 //            workgroup scan -> exclusive chunk prefixes Bq / Be and the chunk energies Te in LDS (4 KB);
 //   coarse   (all threads)  P, E, R at the chunk's first lag are prefix differences.  Over the chunk's 10 lags
@@ -645,12 +309,16 @@ static size_t sc_slide_lds_bytes(int L, int wg, long long frame_len) { // raw sa
 //            prefix differences, <= 4e-6 x the largest prefix, charged against them) CANNOT hold a crossing and are
 //            never looked at again.  On noise and on data symbols the bound is ~0.03, so only the chunks where the
 //            periodic header enters the window are flagged;
-//   fine     (ONE wavefront, rotating per frame so the four SIMDs share the work)  the 64 chunks from the first
-//            flagged one on: slide the window over the chunk's 10 lags from the raw samples in LDS (as k_sc_slide),
-//            first crossing by ballot, window maximum by a wavefront reduction, <= 4 candidates re-evaluated in f64
-//            from the same LDS samples, results written directly (no window hand-off, no finish kernel).
-// Anything the filter cannot settle (ambiguous crossing, > 4 candidates) goes to the slow list as before.
-// LDS: raw samples (18 KB for a 2176-sample frame) + 4.3 KB -> seven workgroups per CU by LDS.
+//   fine     (ONE wavefront, rotating per frame so the SIMDs share the work)  the 32 chunks (320 lags) from the first
+//            flagged one on: each lane slides the window over 5 lags from a chunk boundary, recomputing the entering and
+//            leaving products from the raw samples in LDS; first crossing by ballot, window maximum by a DPP max-scan,
+//            <= 4 candidates re-evaluated in f64 from the same LDS samples.  The exact sums go to k_sc_post, which
+//            turns them into CFO and metric one LANE per frame (an f64 atan2 costs the same for 64 frames as for one).
+// Anything the filter cannot settle (ambiguous crossing, > 4 candidates) goes to the slow list.
+// LDS: raw samples (18 KB for a 2176-sample frame) + 4.3 KB -> seven workgroups per CU.  Measured (OFDM_SC_DEBUG=10..17,
+// tools/sc_sections.py): per frame the DMA wait, phase 1, bases, coarse and fine sections take about 1.0 / 2.0 / 0.7 /
+// 1.3 / 6.0 thousand s_memtime ticks; the fine wavefront is the critical path, which is why its LDS reads are issued
+// up front (one round trip per stage) and its reductions never touch LDS.
 // maximum of non-negative values over the wavefront, DPP only (no LDS round trips): a max-scan leaves it in lane 63
 __device__ __forceinline__ float wave_max_nonneg(float x) {
     x = fmaxf(x, dpp_s<0x111, 0xF>(x));
@@ -979,179 +647,55 @@ static size_t sc_cf_lds_bytes(int L, int nch, long long frame_len) { // raw samp
            16 * sizeof(float) + 64 + 16;
 }
 
-// Exact decision for the frames the filter settled: one wavefront per frame.  It takes the f32 window maximum, keeps the
-// lags within 2 EPS of it (plus the untrusted ones), re-evaluates those (<= 4) lags in f64 from global memory
-// (2 x W samples each, coalesced), keeps the first maximum, and writes timing, CFO and metric.  More than 4 candidates
-// (flat or untrusted windows) go to the slow list, which k_sc_tile redoes entirely in f64 afterwards.
-__global__ __launch_bounds__(256) void k_sc_finish(const ScRec *rec, const float *mwin, int wstride, const cf *in, long long n_frames,
-                                                   long long frame_stride, int L, int W, int32_t *d_hat, double *f_delta,
-                                                   float *metric, int32_t *slow_list, int32_t *slow_count) {
-    const int lane = threadIdx.x & 63;
-    const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= n_frames) return;
-    const ScRec r = rec[f];
-    if (r.state == -2) return; // already on the slow list
-    if (r.state != 1 || r.nwin <= 0) {
-        if (lane == 0) { d_hat[f] = -1; if (f_delta) f_delta[f] = 0.0; if (metric) metric[f] = 0.f; }
-        return;
-    }
-    const float *mw = mwin + f * wstride;
-    const int chunks = (r.nwin + 63) >> 6; // wave-uniform
-    float mmax = 0.f;
-    for (int c = 0; c < chunks; ++c) {
-        const int i = c * 64 + lane;
-        const float m = i < r.nwin ? mw[i] : -1.f;
-        if (m < 3.0e38f) mmax = fmaxf(mmax, m); // untrusted lags (+inf) do not define the maximum
-    }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, s, 64));
-    const float mcut = mmax * (1.f - 2.f * SC_EPS);
-    int cand[SC_MAXCAND];
-    int cnt = 0;
-    for (int c = 0; c < chunks; ++c) {
-        const int i = c * 64 + lane;
-        const float m = i < r.nwin ? mw[i] : -1.f;
-        unsigned long long mask = __ballot(m >= 0.f && (m >= mcut || m > 3.0e38f));
-        while (mask) { // wave-uniform scalar loop over the set bits
-            const int bit = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            if (cnt < SC_MAXCAND) cand[cnt] = r.d1 + c * 64 + bit;
-            ++cnt;
-        }
-    }
-    if (cnt == 0 || cnt > SC_MAXCAND) {
-        if (lane == 0) { d_hat[f] = -1; if (cnt) slow_list[atomicAdd(slow_count, 1)] = (int32_t)f; else { if (f_delta) f_delta[f] = 0.0; if (metric) metric[f] = 0.f; } }
-        return;
-    }
-    const cf *src = in + f * frame_stride;
-    Cand best = Cand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
-#pragma unroll
-    for (int i = 0; i < SC_MAXCAND; ++i) {
-        if (i >= cnt) break;
-        const int d = cand[i];
-        double xr = 0, xi = 0, xe = 0, xq = 0;
-        for (int m = lane; m < W; m += 64) {
-            const cf sa = src[d + m], sb = src[d + m + L];
-            const double ar = sa.x, ai = sa.y, br = sb.x, bi = sb.y;
-            xr += ar * br + ai * bi;
-            xi += ar * bi - ai * br;
-            xe += ar * ar + ai * ai;
-            xq += br * br + bi * bi;
-        }
-        xr = readlane_d(wave_scan(xr), 63); xi = readlane_d(wave_scan(xi), 63);
-        xe = readlane_d(wave_scan(xe), 63); xq = readlane_d(wave_scan(xq), 63);
-        const double xn = xr * xr + xi * xi, xd = xe * xq;
-        if (xd > 0.0) { // candidates arrive in increasing lag order: strictly greater replaces (first maximum wins)
-            if (xn * best.den > best.num * xd) best = Cand{xn, xd, xr, xi, d};
-        }
-    }
-    if (lane == 0) {
-        const bool found = best.lag != INT_MAX;
-        d_hat[f] = found ? best.lag : -1;
-        if (f_delta) f_delta[f] = found ? atan2(best.pi, best.pr) / (double)L : 0.0;
-        if (metric) metric[f] = found ? (float)(best.num / best.den) : 0.f;
-    }
-}
-
-static size_t sc_fast_lds_bytes(int L, int wg, long long frame_len) { // raw samples + q and e prefixes + bases
-    long long n = ((frame_len + 1) / 2 * 2 + 9) / 10 * 10; // staged samples in whole 10-sample chunks (k_sc_fast2: ns)
-    if (n > (long long)wg * 10) n = (long long)wg * 10;
-    return (size_t)(n + L) * sizeof(float2) + (size_t)n * (sizeof(float2) + sizeof(float)) +
-           (size_t)wg * (sizeof(float2) + sizeof(float)) + 16 * sizeof(float) * 2 + 16 * sizeof(int) + 16;
-}
-// smallest workgroup (128 / 256 threads, 10 samples each) whose tile covers the searched lags plus the window
-static int sc_fast_pick_wg(const ScParams &p) {
-    static const int min_wg = [] { const char *e = getenv("OFDM_SC_MIN_WG"); return e ? atoi(e) : 128; }(); // tuning knob
-    for (int wg = min_wg; wg <= 256; wg *= 2)
-        if ((long long)wg * 10 - p.W - p.L >= p.n_lags) return wg;
+// chunks per frame (128 / 256, 10 samples each): the smallest tile that covers the searched lags plus the window
+static int sc_fast_pick_nch(const ScParams &p) {
+    for (int nch = 128; nch <= 256; nch *= 2)
+        if ((long long)nch * 10 - p.W - p.L >= p.n_lags) return nch;
     return 0;
 }
 bool sc_fast_ok(const ScParams &p) {
-    // one tile per frame, 10 | L, 16-byte aligned even-length frames
-    const int wg = sc_fast_pick_wg(p);
-    return p.mode == 0 && wg != 0 && p.L % 10 == 0 && p.W % 10 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 &&
-           (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0 && sc_fast_lds_bytes(p.L, wg, p.frame_len) <= 64 * 1024;
+    // one tile per frame, 10 | L, 10 | W, 16-byte aligned even-length frames, and a peak window (W + 1 lags) that the
+    // fine pass (320 lags from the first flagged chunk) can cover
+    return p.mode == 0 && sc_fast_pick_nch(p) != 0 && p.L % 10 == 0 && p.W % 10 == 0 && p.W + 20 <= 320 &&
+           (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0;
 }
-static int sc_wstride(int W) { return ((W + 1 + 63) / 64) * 64; }
-size_t sc_fast_workspace_bytes(long long n_frames, int W) {
-    static_assert(sizeof(ScExact) >= sizeof(ScRec), "k_sc_cf's records alias the previous generation's");
-    return (size_t)n_frames * (sizeof(ScExact) + sizeof(int32_t) + sizeof(float) * (size_t)sc_wstride(W)) + 64;
+size_t sc_fast_workspace_bytes(long long n_frames, int /*W*/) {
+    return (size_t)n_frames * (sizeof(ScExact) + sizeof(int32_t)) + 64; // exact sums + slow list (+ its counter)
 }
 
 // p.mode == 0, p.tiles_per_frame == 1.  workspace: sc_fast_workspace_bytes(n_frames) bytes of device memory.
 hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st) {
     if (p.n_frames <= 0) return hipSuccess;
-    const int wg = sc_fast_pick_wg(p);
-    const size_t lds = sc_fast_lds_bytes(p.L, wg, p.frame_len);
-    ScRec *rec = reinterpret_cast<ScRec *>(workspace);
-    const int wstride = sc_wstride(p.W);
-    float *mwin = reinterpret_cast<float *>(rec + p.n_frames);
-    int32_t *slow_count = reinterpret_cast<int32_t *>(mwin + (size_t)p.n_frames * wstride);
+    const int nch = sc_fast_pick_nch(p);
+    ScExact *exact = reinterpret_cast<ScExact *>(workspace);
+    int32_t *slow_count = reinterpret_cast<int32_t *>(exact + p.n_frames);
     int32_t *slow_list = slow_count + 4;
     hipError_t e = hipMemsetAsync(slow_count, 0, 16, st);
     if (e != hipSuccess) return e;
     ScFastParams q;
     q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride;
-    const long long tile_n = (long long)wg * 10;
+    const long long tile_n = (long long)nch * 10;
     const long long stage = p.frame_len < tile_n ? p.frame_len : tile_n;
     q.n16 = (int)(stage / 2);
     q.n_lags = (int)p.n_lags; q.L = p.L; q.W = p.W;
-    q.thr = p.threshold;
-    { const char *e = getenv("OFDM_SC_DEBUG"); q.debug = e ? atoi(e) : 0; }
+    { const char *dbg = getenv("OFDM_SC_DEBUG"); q.debug = dbg ? atoi(dbg) : 0; }
     q.thr_lo = (float)(p.threshold * (1.0 - (double)SC_EPS));
     q.thr_hi = (float)(p.threshold * (1.0 + (double)SC_EPS));
-    q.d_hat = p.d_hat; q.rec = rec; q.mwin = mwin; q.wstride = wstride; q.slow_list = slow_list; q.slow_count = slow_count;
-    // persistent over the frame list; workgroups per CU: LDS-bound and capped at 16 waves per CU (128 VGPRs)
+    q.d_hat = p.d_hat; q.slow_list = slow_list; q.slow_count = slow_count; q.exact = exact;
+    // persistent over the frames; workgroups per CU bounded by LDS (22.5 KB for a 2176-sample frame -> 7)
+    static const int per_cu_cap = [] { const char *v = getenv("OFDM_SC_WG_PER_CU"); return v ? atoi(v) : 7; }(); // tuning knob
+    const size_t lds = sc_cf_lds_bytes(p.L, nch, p.frame_len);
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
-    if (per_cu > 768 / wg) per_cu = 768 / wg; // ~150 VGPRs -> 3 waves per SIMD -> 12 waves per CU (4 with spills measured slower)
+    if (per_cu > per_cu_cap) per_cu = per_cu_cap;
+    if (per_cu < 1) per_cu = 1;
     long long grid = (long long)num_cu * per_cu;
     if (grid > p.n_frames) grid = p.n_frames;
-    static const int slide = [] { const char *e = getenv("OFDM_SC_SLIDE"); return e ? atoi(e) : 0; }(); // A/B knob: workgroups per CU
-    static const int cfk = [] { const char *e = getenv("OFDM_SC_CF"); return e ? atoi(e) : 7; }(); // workgroups per CU; 0 = previous generation
-    if (cfk > 0 && p.W + 2 * 10 <= 320) { // the fine pass looks at 320 lags from the first flagged chunk
-        ScExact *exact = reinterpret_cast<ScExact *>(workspace); // aliases rec / mwin of the previous generation
-        q.exact = exact;
-        q.slow_count = reinterpret_cast<int32_t *>(exact + p.n_frames);
-        q.slow_list = q.slow_count + 4;
-        slow_count = q.slow_count; slow_list = q.slow_list;
-        if ((e = hipMemsetAsync(slow_count, 0, 16, st)) != hipSuccess) return e;
-        const size_t l4 = sc_cf_lds_bytes(p.L, wg, p.frame_len);
-        long long pc = (long long)(160 * 1024) / (long long)l4;
-        if (pc > cfk) pc = cfk;
-        grid = (long long)num_cu * pc;
-        if (grid > p.n_frames) grid = p.n_frames;
-        static const int cpt = [] { const char *e = getenv("OFDM_SC_CPT"); return e ? atoi(e) : 2; }(); // A/B knob: chunks per thread
-        if (wg == 256) {
-            if (cpt == 2) {
-                hipLaunchKernelGGL((k_sc_cf<256, 2, 4>), dim3((unsigned)grid), dim3(128), l4, st, q); // <= 7 x 2 waves per CU
-            } else if (cpt == 4) hipLaunchKernelGGL((k_sc_cf<256, 4, 2>), dim3((unsigned)grid), dim3(64), l4, st, q);
-            else if (cfk >= 6) hipLaunchKernelGGL((k_sc_cf<256, 1, 6>), dim3((unsigned)grid), dim3(256), l4, st, q);
-            else if (cfk == 5) hipLaunchKernelGGL((k_sc_cf<256, 1, 5>), dim3((unsigned)grid), dim3(256), l4, st, q);
-            else hipLaunchKernelGGL((k_sc_cf<256, 1, 4>), dim3((unsigned)grid), dim3(256), l4, st, q);
-        } else if (cpt >= 2) hipLaunchKernelGGL((k_sc_cf<128, 2, 2>), dim3((unsigned)grid), dim3(64), l4, st, q);
-        else hipLaunchKernelGGL((k_sc_cf<128, 1, 5>), dim3((unsigned)grid), dim3(128), l4, st, q);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_sc_post, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, p.d_hat, exact, p.n_frames, p.L,
-                           p.f_delta, p.metric);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        goto slow_pass;
-    }
-    if (slide > 0 && wg == 256) {
-        const size_t l3 = sc_slide_lds_bytes(p.L, wg, p.frame_len);
-        long long pc = (long long)(160 * 1024) / (long long)l3;
-        if (pc > slide) pc = slide;
-        grid = (long long)num_cu * pc;
-        if (grid > p.n_frames) grid = p.n_frames;
-        if (slide >= 6) hipLaunchKernelGGL((k_sc_slide<256, 6>), dim3((unsigned)grid), dim3(256), l3, st, q);
-        else if (slide == 5) hipLaunchKernelGGL((k_sc_slide<256, 5>), dim3((unsigned)grid), dim3(256), l3, st, q);
-        else hipLaunchKernelGGL((k_sc_slide<256, 4>), dim3((unsigned)grid), dim3(256), l3, st, q);
-    } else if (wg == 256) hipLaunchKernelGGL(k_sc_fast2<256>, dim3((unsigned)grid), dim3(256), lds, st, q);
-    else hipLaunchKernelGGL(k_sc_fast2<128>, dim3((unsigned)grid), dim3(128), lds, st, q);
+    if (nch == 256) hipLaunchKernelGGL((k_sc_cf<256, 2, 4>), dim3((unsigned)grid), dim3(128), lds, st, q); // <= 7 x 2 waves per CU
+    else hipLaunchKernelGGL((k_sc_cf<128, 2, 2>), dim3((unsigned)grid), dim3(64), lds, st, q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sc_finish, dim3((unsigned)((p.n_frames + 3) / 4)), dim3(256), 0, st, rec, mwin, wstride, p.in, p.n_frames,
-                       p.frame_stride, p.L, p.W, p.d_hat, p.f_delta, p.metric, slow_list, slow_count);
+    hipLaunchKernelGGL(k_sc_post, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, p.d_hat, exact, p.n_frames, p.L,
+                       p.f_delta, p.metric);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-slow_pass:
     // frames the filter could not settle: all-f64 kernel over the device-side list (usually empty)
     ScParams s = p;
     s.slow_list = slow_list; s.slow_count = slow_count; s.tiles_per_frame = 1; s.mode = 0;

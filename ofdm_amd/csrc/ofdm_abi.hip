@@ -408,7 +408,7 @@ static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame
     p.in = in; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len; p.n_lags = n_lags;
     p.L = L; p.W = W; p.threshold = (double)c->prm.sync_threshold;
     p.d_hat = d_hat; p.f_delta = f_delta; p.metric = metric;
-    // one-tile frames with a short period: f32 filter + exact f64 decisions (k_sc_fast)
+    // one-tile frames with a short period: coarse-then-fine f32 filter + exact f64 decisions (k_sc_cf)
     p.tiles_per_frame = 1; p.mode = 0;
     if (sc_fast_ok(p)) {
         void *wsp;
