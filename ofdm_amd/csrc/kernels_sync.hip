@@ -691,7 +691,13 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     long long grid = (long long)num_cu * per_cu;
     if (grid > p.n_frames) grid = p.n_frames;
     if (nch == 256) hipLaunchKernelGGL((k_sc_cf<256, 2, 4>), dim3((unsigned)grid), dim3(128), lds, st, q); // <= 7 x 2 waves per CU
-    else hipLaunchKernelGGL((k_sc_cf<128, 2, 2>), dim3((unsigned)grid), dim3(64), lds, st, q);
+    else { // 128-chunk tile (bounded searches): 128 threads, one chunk each, up to 10 workgroups per CU (measured best)
+        per_cu = (long long)(160 * 1024) / (long long)lds;
+        if (per_cu > 10) per_cu = 10;
+        grid = (long long)num_cu * per_cu;
+        if (grid > p.n_frames) grid = p.n_frames;
+        hipLaunchKernelGGL((k_sc_cf<128, 1, 5>), dim3((unsigned)grid), dim3(128), lds, st, q);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(k_sc_post, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, p.d_hat, exact, p.n_frames, p.L,
                        p.f_delta, p.metric);
