@@ -20,7 +20,7 @@
  *     cost ~1e-5 rad of phase by the end of a 2000-sample frame.
  *   - pilot tables (preamble, training) are INPUTS: the reference draws them from rand 0.8 StdRng
  *     (src/transmitter.rs:75-96), which cannot be verified offline; ofdm_default_pilots() supplies the
- *     documented SplitMix64 defaults.
+ *     documented SplitMix64 defaults and ofdm_stdrng_pilots() a restatement of the StdRng tables.
  *
  * Extensions named by the north star that the reference lacks (64/256-QAM, Hamming(7,4), Schmidl-Cox,
  * N != 64) are defined in DESIGN.md section 3 and restated on the CPU in oracle/ofdm_oracle.c.
@@ -85,6 +85,14 @@ int ofdm_default_params(ofdm_params *p);
 /* SplitMix64 pilot tables (interleaved re,im doubles): preamble[2*(n_fft+cp)] = 0.25*U(-1,1) seed 100
  * (src/transmitter.rs:75-84), training[2*n_fft] = U(-1,1) seed 50 (src/transmitter.rs:88-96). Host call. */
 int ofdm_default_pilots(int32_t n_fft, int32_t cp_len, double *preamble, double *training);
+/* The reference's own tables: rand 0.8 StdRng (ChaCha12, seed_from_u64(100) / (50), gen_range(-1.0..1.0), re before im;
+ * src/transmitter.rs:75-96) restated from the published algorithm.  Same layout as ofdm_default_pilots.  Needed only to
+ * decode captures produced by the real Rust transmitter; UNVERIFIED against a running `rand` (none exists offline).
+ * Host call. */
+int ofdm_stdrng_pilots(int32_t n_fft, int32_t cp_len, double *preamble, double *training);
+/* One ChaCha block (16 words out) from key[8] and state words 12..15, `rounds` = 8 / 12 / 20: exported so that the
+ * published test vectors can pin the generator core. Host call. */
+int ofdm_chacha_block(const uint32_t *key8, const uint32_t *words12_15, int32_t rounds, uint32_t *out16);
 /* preamble / training: host pointers (interleaved doubles) or NULL for the defaults.
  * device: HIP device ordinal.  stream: a hipStream_t (as void*); NULL = the device's default (null) stream,
  * which is what torch uses as its current stream unless told otherwise. */

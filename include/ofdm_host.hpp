@@ -28,14 +28,28 @@ inline void check(int rc, const char *what) {
 }
 
 // RAII context = one (thread, GPU) handle
+// which preamble / training tables a context is built with (src/transmitter.rs:75-96)
+enum class Pilots {
+    Default, // documented SplitMix64 draws (ofdm_default_pilots)
+    StdRng,  // the reference's own rand 0.8 StdRng draws, restated and unverified (ofdm_stdrng_pilots)
+};
+inline Pilots &default_pilot_choice() { static Pilots p = Pilots::Default; return p; } // used by the free encode / decode
+
 class Context {
   public:
     explicit Context(bool guard_bands = false, ModulationScheme m = ModulationScheme::Bpsk, int n_fft = 64,
-                     int ecc = OFDM_ECC_NONE, int cfo_mode = OFDM_CFO_SIGNED, int device = 0) {
+                     int ecc = OFDM_ECC_NONE, int cfo_mode = OFDM_CFO_SIGNED, int device = 0,
+                     Pilots pilots = default_pilot_choice()) {
         ofdm_params p;
         check(ofdm_default_params(&p), "ofdm_default_params");
         p.n_fft = n_fft; p.cp_len = n_fft / 4; p.guard_bands = guard_bands; p.modulation = (int)m; p.ecc = ecc; p.cfo_mode = cfo_mode;
-        check(ofdm_create(&p, nullptr, nullptr, device, nullptr, &ctx_), "ofdm_create");
+        if (pilots == Pilots::StdRng) {
+            std::vector<double> pre(2 * (size_t)(n_fft + n_fft / 4)), trn(2 * (size_t)n_fft);
+            check(ofdm_stdrng_pilots(n_fft, n_fft / 4, pre.data(), trn.data()), "ofdm_stdrng_pilots");
+            check(ofdm_create(&p, pre.data(), trn.data(), device, nullptr, &ctx_), "ofdm_create");
+        } else {
+            check(ofdm_create(&p, nullptr, nullptr, device, nullptr, &ctx_), "ofdm_create");
+        }
     }
     ~Context() { ofdm_destroy(ctx_); }
     Context(const Context &) = delete;

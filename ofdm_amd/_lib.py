@@ -28,6 +28,8 @@ SIGNATURES = {
     "ofdm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "ofdm_default_params": (C.c_int, [C.POINTER(Params)]),
     "ofdm_default_pilots": (C.c_int, [i32, i32, vp, vp]),
+    "ofdm_stdrng_pilots": (C.c_int, [i32, i32, vp, vp]),
+    "ofdm_chacha_block": (C.c_int, [vp, vp, i32, vp]),
     "ofdm_create": (C.c_int, [C.POINTER(Params), vp, vp, C.c_int, vp, C.POINTER(vp)]),
     "ofdm_destroy": (C.c_int, [vp]),
     "ofdm_set_stream": (C.c_int, [vp, vp]),

@@ -48,6 +48,17 @@ def default_pilots(n_fft: int = 64):
     return pre, trn
 
 
+def stdrng_pilots(n_fft: int = 64):
+    """(preamble[n_fft+cp], training[n_fft]) as the reference draws them: rand 0.8 StdRng (ChaCha12), seeds 100 / 50
+    (src/transmitter.rs:75-96).  Restated from the published algorithm; unverified against a running `rand`."""
+    lib = _lib.load()
+    cp = n_fft // 4
+    pre = np.zeros(n_fft + cp, np.complex128)
+    trn = np.zeros(n_fft, np.complex128)
+    _check(lib, lib.ofdm_stdrng_pilots(n_fft, cp, pre.ctypes.data, trn.ctypes.data), "ofdm_stdrng_pilots")
+    return pre, trn
+
+
 def locking_signal(length: int = 80) -> np.ndarray:
     """src/transmitter.rs:60-72 (host-side constant; the library builds the same table into its frame header)."""
     v = 0.5 * (np.arange(length) / (2.0 * length) + 0.5)
@@ -72,8 +83,14 @@ class Context:
     def __init__(self, n_fft: int = 64, modulation: int = BPSK, guard_bands: bool = False, ecc: int = ECC_NONE,
                  device: int = 0, preamble: Optional[np.ndarray] = None, training: Optional[np.ndarray] = None,
                  sync_window_reps: int = 3, sync_backoff: int = 4, cfo_mode: int = CFO_SIGNED,
-                 sync_threshold: float = 0.5, use_torch_stream: bool = True):
+                 sync_threshold: float = 0.5, use_torch_stream: bool = True, pilots: str = "default"):
         self.lib = _lib.load()
+        if pilots == "stdrng":  # the reference's own tables (restated, unverified) unless explicit tables are given
+            sp, st = stdrng_pilots(n_fft)
+            preamble = sp if preamble is None else preamble
+            training = st if training is None else training
+        elif pilots != "default":
+            raise OfdmError("pilots must be 'default' or 'stdrng'")
         if not torch.cuda.is_available():
             raise OfdmError("no GPU visible: the OFDM hot path has no CPU fallback")
         self.device = torch.device("cuda", device)
@@ -339,10 +356,10 @@ def _ctx(n_fft, modulation, guard_bands, ecc=ECC_NONE, **kw) -> Context:
 
 
 def encode(data: bytes, guard_bands: Optional[bool] = None, modulation: Optional[int] = None, n_fft: int = 64,
-           ecc: int = ECC_NONE) -> np.ndarray:
+           ecc: int = ECC_NONE, **kw) -> np.ndarray:
     """`ofdm::encode!(data, guard_bands, modulation)` (src/transmitter.rs:10-58): bytes -> Vec<Complex64>.
     Defaults as the reference: guard_bands=false, modulation=Bpsk."""
-    ctx = _ctx(n_fft, BPSK if modulation is None else modulation, bool(guard_bands), ecc)
+    ctx = _ctx(n_fft, BPSK if modulation is None else modulation, bool(guard_bands), ecc, **kw)
     pay = torch.frombuffer(bytearray(data) if len(data) else bytearray(1), dtype=torch.uint8)[: len(data)]
     pay = pay.reshape(1, len(data)).to(ctx.device)
     frames = ctx.encode_batch(pay)

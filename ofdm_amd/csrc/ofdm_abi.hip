@@ -173,6 +173,90 @@ int ofdm_default_pilots(int32_t n_fft, int32_t cp_len, double *preamble, double 
     return OFDM_OK;
 }
 
+// ---- rand 0.8 `StdRng` (= ChaCha12Rng of rand_chacha 0.3) restated from the crates' published algorithm, for the
+// reference's pilot tables (src/transmitter.rs:75-96).  The ChaCha core is pinned by the published RFC 7539 / ChaCha12
+// test vectors (tests/test_abi_cpu.py); seeding (rand_core 0.6 seed_from_u64: PCG32 expansion) and the f64
+// gen_range(-1.0..1.0) mapping (rand 0.8.3 UniformFloat::sample_single: 52 mantissa bits -> [1,2) - 1, * scale + low)
+// cannot be checked against a running `rand` here: the tables are "unverified" (DESIGN.md section 2).
+namespace {
+struct StdRng {
+    uint32_t key[8];
+    uint64_t counter = 0;
+    uint32_t buf[16];
+    int idx = 16;
+    static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+    static void qr(uint32_t *s, int a, int b, int c, int d) {
+        s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 16);
+        s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 12);
+        s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 8);
+        s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 7);
+    }
+    static void block(const uint32_t key[8], const uint32_t w12_15[4], int rounds, uint32_t out[16]) {
+        uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+        for (int i = 0; i < 8; i++) st[4 + i] = key[i];
+        for (int i = 0; i < 4; i++) st[12 + i] = w12_15[i];
+        uint32_t s[16];
+        for (int i = 0; i < 16; i++) s[i] = st[i];
+        for (int r = 0; r < rounds / 2; r++) {
+            qr(s, 0, 4, 8, 12); qr(s, 1, 5, 9, 13); qr(s, 2, 6, 10, 14); qr(s, 3, 7, 11, 15);
+            qr(s, 0, 5, 10, 15); qr(s, 1, 6, 11, 12); qr(s, 2, 7, 8, 13); qr(s, 3, 4, 9, 14);
+        }
+        for (int i = 0; i < 16; i++) out[i] = s[i] + st[i];
+    }
+    explicit StdRng(uint64_t state) { // SeedableRng::seed_from_u64: PCG32 output per 4 seed bytes (little endian)
+        for (int i = 0; i < 8; i++) {
+            state = state * 6364136223846793005ull + 11634580027462260723ull;
+            const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+            const uint32_t rot = (uint32_t)(state >> 59);
+            key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        }
+    }
+    uint32_t next_u32() {
+        if (idx == 16) { // 64-bit block counter in words 12-13, stream id 0 in words 14-15
+            const uint32_t w[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+            block(key, w, 12, buf);
+            ++counter;
+            idx = 0;
+        }
+        return buf[idx++];
+    }
+    uint64_t next_u64() { const uint64_t lo = next_u32(); return lo | ((uint64_t)next_u32() << 32); } // BlockRng: low word first
+    double range_pm1() { // gen_range(-1.0..1.0)
+        const uint64_t bits = (next_u64() >> 12) | 0x3ff0000000000000ull;
+        double v;
+        std::memcpy(&v, &bits, 8);
+        return (v - 1.0) * 2.0 + -1.0;
+    }
+};
+} // namespace
+
+int ofdm_stdrng_pilots(int32_t n_fft, int32_t cp_len, double *preamble, double *training) {
+    if (!valid_nfft(n_fft) || cp_len != n_fft / 4) return OFDM_ERR_INVALID;
+    if (preamble) {
+        StdRng r(100); // transmitter.rs:76
+        for (int i = 0; i < n_fft + cp_len; i++) {
+            const double re = r.range_pm1(), im = r.range_pm1(); // re drawn before im (transmitter.rs:80)
+            preamble[2 * i] = re * 0.25;
+            preamble[2 * i + 1] = im * 0.25;
+        }
+    }
+    if (training) {
+        StdRng r(50); // transmitter.rs:89
+        for (int i = 0; i < n_fft; i++) {
+            const double re = r.range_pm1(), im = r.range_pm1();
+            training[2 * i] = re;
+            training[2 * i + 1] = im;
+        }
+    }
+    return OFDM_OK;
+}
+
+int ofdm_chacha_block(const uint32_t *key8, const uint32_t *words12_15, int32_t rounds, uint32_t *out16) {
+    if (!key8 || !words12_15 || !out16 || rounds <= 0 || (rounds & 1)) return OFDM_ERR_INVALID;
+    StdRng::block(key8, words12_15, rounds, out16);
+    return OFDM_OK;
+}
+
 int ofdm_destroy(ofdm_ctx *c) {
     if (!c) return OFDM_OK;
     hipSetDevice(c->device);

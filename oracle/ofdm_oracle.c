@@ -228,6 +228,71 @@ void orc_default_training(int len, oc64 *out) {
     }
 }
 
+/* ------------------------------------------------------------------ rand 0.8 StdRng restated (ChaCha12 keystream)
+ * transmitter.rs:76-80,89-93 draw the pilot tables from rand::rngs::StdRng::seed_from_u64(seed) with
+ * gen_range(-1.0..1.0).  rand = "0.8.3" (Cargo.toml:23; Cargo.lock is git-ignored) is not under /root/reference, so
+ * this follows the crates' published algorithm: rand_core 0.6 seed_from_u64 (PCG32 per 4 key bytes), rand_chacha 0.3
+ * ChaCha12 with a 64-bit block counter and stream id 0, BlockRng::next_u64 = two consecutive keystream words (low
+ * first), UniformFloat<f64>::sample_single = ((u64 >> 12) as mantissa of [1,2)) - 1, then * (high-low) + low.
+ * The keystream is pinned by published ChaCha vectors in the tests; the rest is unverified ("parity unpinned"). */
+typedef struct { uint32_t in[16]; uint32_t ks[16]; int used; } orc_stdrng;
+#define ORC_ROTL(v, n) (((v) << (n)) | ((v) >> (32 - (n))))
+#define ORC_QR(a, b, c, d) \
+    a += b; d ^= a; d = ORC_ROTL(d, 16); c += d; b ^= c; b = ORC_ROTL(b, 12); \
+    a += b; d ^= a; d = ORC_ROTL(d, 8);  c += d; b ^= c; b = ORC_ROTL(b, 7);
+void orc_chacha_keystream_block(const uint32_t in[16], int rounds, uint32_t out[16]) {
+    uint32_t x0 = in[0], x1 = in[1], x2 = in[2], x3 = in[3], x4 = in[4], x5 = in[5], x6 = in[6], x7 = in[7], x8 = in[8],
+             x9 = in[9], x10 = in[10], x11 = in[11], x12 = in[12], x13 = in[13], x14 = in[14], x15 = in[15];
+    for (int i = rounds; i > 0; i -= 2) {
+        ORC_QR(x0, x4, x8, x12) ORC_QR(x1, x5, x9, x13) ORC_QR(x2, x6, x10, x14) ORC_QR(x3, x7, x11, x15)
+        ORC_QR(x0, x5, x10, x15) ORC_QR(x1, x6, x11, x12) ORC_QR(x2, x7, x8, x13) ORC_QR(x3, x4, x9, x14)
+    }
+    const uint32_t x[16] = {x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15};
+    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
+}
+static void orc_stdrng_seed(orc_stdrng *r, uint64_t seed) {
+    static const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u}; /* "expand 32-byte k" */
+    for (int i = 0; i < 4; i++) r->in[i] = sigma[i];
+    uint64_t pcg = seed;
+    for (int i = 0; i < 8; i++) {
+        pcg = pcg * 6364136223846793005ULL + 11634580027462260723ULL;
+        uint32_t xs = (uint32_t)(((pcg >> 18) ^ pcg) >> 27), rot = (uint32_t)(pcg >> 59);
+        r->in[4 + i] = rot ? ((xs >> rot) | (xs << (32 - rot))) : xs;
+    }
+    r->in[12] = r->in[13] = r->in[14] = r->in[15] = 0;
+    r->used = 16;
+}
+static uint32_t orc_stdrng_word(orc_stdrng *r) {
+    if (r->used == 16) {
+        orc_chacha_keystream_block(r->in, 12, r->ks);
+        if (++r->in[12] == 0) ++r->in[13];
+        r->used = 0;
+    }
+    return r->ks[r->used++];
+}
+static double orc_stdrng_pm1(orc_stdrng *r) {
+    uint64_t lo = orc_stdrng_word(r), hi = orc_stdrng_word(r);
+    union { uint64_t u; double d; } v;
+    v.u = (((hi << 32) | lo) >> 12) | ((uint64_t)1023 << 52);
+    return (v.d - 1.0) * (1.0 - -1.0) + -1.0;
+}
+void orc_stdrng_preamble(int len, oc64 *out) {
+    orc_stdrng r;
+    orc_stdrng_seed(&r, 100);
+    for (int i = 0; i < len; i++) {
+        double re = orc_stdrng_pm1(&r), im = orc_stdrng_pm1(&r);
+        out[i] = c_scale(c_new(re, im), 0.25);
+    }
+}
+void orc_stdrng_training(int len, oc64 *out) {
+    orc_stdrng r;
+    orc_stdrng_seed(&r, 50);
+    for (int i = 0; i < len; i++) {
+        double re = orc_stdrng_pm1(&r), im = orc_stdrng_pm1(&r);
+        out[i] = c_scale(c_new(re, im), 1.0);
+    }
+}
+
 static inline int stream_bit(const uint8_t *bytes, size_t nbytes, size_t bit) {
     size_t by = bit >> 3;
     if (by >= nbytes) return 0;

@@ -64,6 +64,9 @@ int orc_data_carriers(int n_fft, int guard);
 void orc_locking_signal(int len, oc64 *out);                    /* transmitter.rs:60-72 */
 void orc_default_preamble(int len, oc64 *out);                  /* transmitter.rs:75-84, SplitMix64 seed 100 */
 void orc_default_training(int len, oc64 *out);                  /* transmitter.rs:88-96, SplitMix64 seed 50 */
+void orc_stdrng_preamble(int len, oc64 *out);                   /* transmitter.rs:75-84 with rand 0.8 StdRng restated (unverified) */
+void orc_stdrng_training(int len, oc64 *out);                   /* transmitter.rs:88-96 with rand 0.8 StdRng restated (unverified) */
+void orc_chacha_keystream_block(const uint32_t in[16], int rounds, uint32_t out[16]); /* pinned by RFC 7539 2.3.2 */
 size_t orc_modulate_count(size_t nbytes, int modulation);
 size_t orc_modulate(const uint8_t *bytes, size_t nbytes, int modulation, oc64 *out); /* transmitter.rs:108-140 + EXT-1 */
 void orc_encode_block(const oc64 *stream, size_t avail, size_t *consumed, int n_fft, int guard,

@@ -193,6 +193,26 @@ def default_training(length=64):
     return out
 
 
+def stdrng_preamble(length=80):
+    """transmitter.rs:75-84 with rand 0.8 StdRng (ChaCha12) restated; unverified against a running `rand`."""
+    out = np.zeros(length, np.complex128)
+    lib().orc_stdrng_preamble(C.c_int(length), _c(out))
+    return out
+
+
+def stdrng_training(length=64):
+    out = np.zeros(length, np.complex128)
+    lib().orc_stdrng_training(C.c_int(length), _c(out))
+    return out
+
+
+def chacha_block(state16, rounds):
+    st = np.ascontiguousarray(state16, dtype=np.uint32)
+    out = np.zeros(16, np.uint32)
+    lib().orc_chacha_keystream_block(st.ctypes.data_as(C.c_void_p), C.c_int(rounds), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 # ---------------------------------------------------------------- TX
 def modulate(data: bytes, modulation: int) -> np.ndarray:
     d = np.frombuffer(bytes(data), np.uint8).copy()

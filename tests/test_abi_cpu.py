@@ -70,6 +70,50 @@ def test_host_entry_points(lib, orc):
     assert lib.ofdm_default_pilots(100, 25, None, None) == -1
 
 
+# ---- 8(f) rank 3: the reference's own pilot tables (rand 0.8 StdRng = ChaCha12) restated
+CHACHA_KATS = [  # published vectors: (key words, state words 12..15, rounds, keystream block hex)
+    # RFC 7539 section 2.3.2 (ChaCha20 block function)
+    (list(np.frombuffer(bytes(range(32)), "<u4")), [1, 0x09000000, 0x4A000000, 0], 20,
+     "10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4ed2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e"),
+    # RFC 7539 appendix A.1 test vector 1 (all-zero key and nonce, counter 0)
+    ([0] * 8, [0, 0, 0, 0], 20,
+     "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586"),
+    # ChaCha12, all-zero 256-bit key and IV (eSTREAM / reference-implementation test vector TC1)
+    ([0] * 8, [0, 0, 0, 0], 12,
+     "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be"),
+]
+
+
+@pytest.mark.parametrize("key,w,rounds,want", CHACHA_KATS)
+def test_chacha_core_published_vectors(lib, orc, key, w, rounds, want):
+    k = np.array(key, np.uint32); ww = np.array(w, np.uint32); out = np.zeros(16, np.uint32)
+    assert lib.ofdm_chacha_block(C.c_void_p(k.ctypes.data), C.c_void_p(ww.ctypes.data), rounds, C.c_void_p(out.ctypes.data)) == 0
+    assert out.astype("<u4").tobytes().hex() == want
+    st = np.array([0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key) + list(w), np.uint32)
+    assert orc.chacha_block(st, rounds).astype("<u4").tobytes().hex() == want  # the oracle's independent core
+    assert lib.ofdm_chacha_block(None, None, 12, None) == -1 and lib.ofdm_chacha_block(C.c_void_p(k.ctypes.data), C.c_void_p(ww.ctypes.data), 7, C.c_void_p(out.ctypes.data)) == -1
+
+
+def test_stdrng_pilots_two_restatements_agree(lib, orc):
+    """Seeding (PCG32 expansion) and the f64 range mapping are restated from rand 0.8.3's published source and cannot be
+    checked against a running `rand` here (parity unpinned); library and oracle implement them independently."""
+    for n in (64, 256, 1024):
+        pre = np.zeros(n + n // 4, np.complex128)
+        trn = np.zeros(n, np.complex128)
+        assert lib.ofdm_stdrng_pilots(n, n // 4, C.c_void_p(pre.ctypes.data), C.c_void_p(trn.ctypes.data)) == 0
+        np.testing.assert_array_equal(pre, orc.stdrng_preamble(n + n // 4))
+        np.testing.assert_array_equal(trn, orc.stdrng_training(n))
+        assert np.abs(pre.real).max() < 0.25 and np.abs(pre.imag).max() < 0.25 and np.abs(trn.real).max() < 1.0
+        # the reference regenerates training with LEN = 80 on RX and uses the first 64 (receiver.rs:216,220): a prefix
+        np.testing.assert_array_equal(orc.stdrng_training(n + n // 4)[:n], trn)
+        assert not np.array_equal(pre, orc.default_preamble(n + n // 4))
+    # U(-1,1) sanity over the whole table: mean ~ 0, variance ~ 1/3
+    t = orc.stdrng_training(4096)
+    v = np.concatenate([t.real, t.imag])
+    assert abs(v.mean()) < 0.03 and abs(v.var() - 1 / 3) < 0.02
+    assert lib.ofdm_stdrng_pilots(100, 25, None, None) == -1
+
+
 def test_create_rejects_bad_params_and_missing_gpu(lib):
     from ofdm_amd import Params
 

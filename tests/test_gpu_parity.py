@@ -395,6 +395,22 @@ def test_loopback_lab3_on_gpu(api, orc, timing_error):
 
 
 # ------------------------------------------------------------------ size-independent properties at large sizes
+def test_stdrng_pilot_tables(api, orc):
+    """8(f) rank 3: contexts built with the restated rand-0.8 StdRng tables (transmitter.rs:75-96); unverified against a
+    running `rand`, but the path must work with them exactly as with any other table."""
+    rng = np.random.default_rng(77)
+    pre, trn = api.stdrng_pilots(64)
+    np.testing.assert_array_equal(pre, orc.stdrng_preamble(80))
+    np.testing.assert_array_equal(trn, orc.stdrng_training(64))
+    pay = bytes(rng.integers(0, 256, 200, dtype=np.uint8))
+    tx = api.encode(pay, True, api.QAM64, pilots="stdrng")
+    assert rel_err(tx, orc.encode(pay, guard=True, modulation=orc.QAM64, preamble=pre, training=trn)) < TOL
+    assert rel_err(tx[80:160], tx[160:240]) == 0 and rel_err(tx, api.encode(pay, True, api.QAM64)) > 0.1  # other tables
+    cap = through_channel(orc, rng, wide(fc32(tx)), 2400, 31, 0.004, snr_db=35.0, data_start=800)
+    assert api.decode(wide(cap), True, api.QAM64, pilots="stdrng") == pay
+    assert bytes(orc.decode_sc(wide(cap), guard=True, modulation=orc.QAM64, training=trn)["bytes"]) == pay
+
+
 def test_large_batch_properties(api, orc):
     """Properties that need no oracle run, at sizes far beyond what the oracle finishes in seconds:
     TX -> RX round trip is the identity on bytes, two independent kernels (wave-centric fast path and the generic
@@ -477,7 +493,8 @@ def test_cpp_host_loopback(ofdm):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(root, "include"),
                            os.path.join(root, "tools", "ofdm_loopback.cpp"), "-L", os.path.join(root, "ofdm_amd"), "-lofdm_hip",
                            "-Wl,-rpath," + os.path.join(root, "ofdm_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
-    for args in ([], ["--timing-error"], ["--guard", "--qam64", "--bytes", "560", "--timing-error"]):
+    for args in ([], ["--timing-error"], ["--guard", "--qam64", "--bytes", "560", "--timing-error"],
+                 ["--pilots", "stdrng", "--timing-error"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, (args, r.stdout, r.stderr)          # exit 0 <=> Analysis.num_errs == 0
         assert "num_errs: 0" in r.stdout and "I met a traveller" in r.stdout

@@ -79,6 +79,8 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(argv[i], "--receive") && i + 1 < argc) rx_file = argv[++i];
         else if (!std::strcmp(argv[i], "--start") && i + 1 < argc) start = std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "--stop") && i + 1 < argc) stop = std::atol(argv[++i]);
+        else if (!std::strcmp(argv[i], "--pilots") && i + 1 < argc)                 // "stdrng": the reference's own tables (restated)
+            default_pilot_choice() = !std::strcmp(argv[++i], "stdrng") ? Pilots::StdRng : Pilots::Default;
     }
     try {
         std::vector<uint8_t> source(num_bytes);
