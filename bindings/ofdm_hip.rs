@@ -35,6 +35,8 @@ extern "C" {
     pub fn ofdm_device_count(count: *mut c_int) -> c_int;
     pub fn ofdm_default_params(p: *mut ofdm_params) -> c_int;
     pub fn ofdm_default_pilots(n_fft: i32, cp_len: i32, preamble: *mut f64, training: *mut f64) -> c_int;
+    pub fn ofdm_stdrng_pilots(n_fft: i32, cp_len: i32, preamble: *mut f64, training: *mut f64) -> c_int;
+    pub fn ofdm_chacha_block(key8: *const u32, words12_15: *const u32, rounds: i32, out16: *mut u32) -> c_int;
     pub fn ofdm_create(p: *const ofdm_params, preamble: *const f64, training: *const f64, device: c_int,
                        stream: *mut c_void, out: *mut *mut ofdm_ctx) -> c_int;
     pub fn ofdm_destroy(ctx: *mut ofdm_ctx) -> c_int;
