@@ -36,6 +36,10 @@ extern "C" {
     pub fn ofdm_default_params(p: *mut ofdm_params) -> c_int;
     pub fn ofdm_default_pilots(n_fft: i32, cp_len: i32, preamble: *mut f64, training: *mut f64) -> c_int;
     pub fn ofdm_stdrng_pilots(n_fft: i32, cp_len: i32, preamble: *mut f64, training: *mut f64) -> c_int;
+    pub fn ofdm_rs255_encoded_len(n_bytes: i64) -> i64;
+    pub fn ofdm_rs255_decoded_len(n_code: i64) -> i64;
+    pub fn ofdm_rs255_encode(data: *const u8, n_bytes: i64, out: *mut u8) -> c_int;
+    pub fn ofdm_rs255_decode(code: *const u8, n_code: i64, out: *mut u8, corrected: *mut i32) -> c_int;
     pub fn ofdm_chacha_block(key8: *const u32, words12_15: *const u32, rounds: i32, out16: *mut u32) -> c_int;
     pub fn ofdm_create(p: *const ofdm_params, preamble: *const f64, training: *const f64, device: c_int,
                        stream: *mut c_void, out: *mut *mut ofdm_ctx) -> c_int;

@@ -47,7 +47,8 @@ enum {
     OFDM_ERR_UNSUPPORTED = -2, /* valid request this build does not implement */
     OFDM_ERR_NO_DEVICE = -3,   /* no HIP device / wrong architecture */
     OFDM_ERR_HIP = -4,         /* a HIP runtime call failed (ofdm_last_hip_error) */
-    OFDM_ERR_NOMEM = -5
+    OFDM_ERR_NOMEM = -5,
+    OFDM_ERR_UNCORRECTABLE = -6 /* outer RS block with more than 16 byte errors (the reference returns None) */
 };
 
 /* per-frame status written by ofdm_rx_decode_batch */
@@ -145,6 +146,17 @@ int ofdm_normalize_batch(ofdm_ctx *ctx, ofdm_fc32 *x_dev, int64_t n_frames, int6
 int ofdm_hamming74_encode(ofdm_ctx *ctx, const uint8_t *in_dev, int64_t n_bytes, uint8_t *out_dev);
 int ofdm_hamming74_decode(ofdm_ctx *ctx, const uint8_t *in_dev, int64_t n_bytes, uint8_t *out_dev,
                           uint32_t *corrected_dev);
+
+/* Outer Reed-Solomon(255,223) framing of the demos (create_transmission_bytes / decipher_transmission_bytes,
+ * src/utils.rs:97-180; reed-solomon 0.2.1: GF(2^8) 0x11d, generator 2, roots 2^0..2^31, parity after the data).
+ * HOST calls on host buffers: byte-level work off the roofline, applied outside encode/decode as the reference does.
+ * encode: n_bytes -> 255*(n/223 + 1) bytes (a final zero-padded block is always emitted, utils.rs:123-131);
+ * decode: n_code -> 223*(n/255 + 1) bytes (the zero-padded remainder is decoded too, utils.rs:172-176), corrects up to
+ * 16 bytes per block, OFDM_ERR_UNCORRECTABLE otherwise; *corrected (optional) = corrected bytes in total. */
+int64_t ofdm_rs255_encoded_len(int64_t n_bytes);
+int64_t ofdm_rs255_decoded_len(int64_t n_code);
+int ofdm_rs255_encode(const uint8_t *data, int64_t n_bytes, uint8_t *out);
+int ofdm_rs255_decode(const uint8_t *code, int64_t n_code, uint8_t *out, int32_t *corrected);
 
 /* Schmidl-Cox sliding autocorrelation (north-star extension replacing xcorr_fft timing, receiver.rs:20-25).
  * Frame f occupies in_dev[f*frame_stride .. +frame_len).  Lags d in [0, n_lags) (n_lags <= 0: every lag with

@@ -145,6 +145,20 @@ inline std::vector<uint8_t> decode(std::vector<Complex64> samples, std::optional
     return c.decode(std::move(samples));
 }
 
+// outer Reed-Solomon(255,223) framing of the demos (src/utils.rs:97-180), host side
+inline std::vector<uint8_t> create_transmission_bytes(const std::vector<uint8_t> &data) { // utils.rs:97-136
+    std::vector<uint8_t> out((size_t)ofdm_rs255_encoded_len((int64_t)data.size()));
+    check(ofdm_rs255_encode(data.data(), (int64_t)data.size(), out.data()), "ofdm_rs255_encode");
+    return out;
+}
+inline std::optional<std::vector<uint8_t>> decipher_transmission_bytes(const std::vector<uint8_t> &code) { // utils.rs:150-180
+    std::vector<uint8_t> out((size_t)ofdm_rs255_decoded_len((int64_t)code.size()));
+    const int rc = ofdm_rs255_decode(code.data(), (int64_t)code.size(), out.data(), nullptr);
+    if (rc == OFDM_ERR_UNCORRECTABLE) return std::nullopt; // the reference returns None
+    check(rc, "ofdm_rs255_decode");
+    return out;
+}
+
 // utils::Analysis (src/utils.rs:38-69)
 struct Analysis {
     uint32_t num_errs = 0, num_block_errs = 0;

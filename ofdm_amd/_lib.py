@@ -30,6 +30,10 @@ SIGNATURES = {
     "ofdm_default_pilots": (C.c_int, [i32, i32, vp, vp]),
     "ofdm_stdrng_pilots": (C.c_int, [i32, i32, vp, vp]),
     "ofdm_chacha_block": (C.c_int, [vp, vp, i32, vp]),
+    "ofdm_rs255_encoded_len": (C.c_int64, [i64]),
+    "ofdm_rs255_decoded_len": (C.c_int64, [i64]),
+    "ofdm_rs255_encode": (C.c_int, [vp, i64, vp]),
+    "ofdm_rs255_decode": (C.c_int, [vp, i64, vp, vp]),
     "ofdm_create": (C.c_int, [C.POINTER(Params), vp, vp, C.c_int, vp, C.POINTER(vp)]),
     "ofdm_destroy": (C.c_int, [vp]),
     "ofdm_set_stream": (C.c_int, [vp, vp]),

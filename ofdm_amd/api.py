@@ -59,6 +59,28 @@ def stdrng_pilots(n_fft: int = 64):
     return pre, trn
 
 
+def create_transmission_bytes(data: bytes) -> bytes:
+    """utils::create_transmission_bytes (src/utils.rs:97-136): outer RS(255,223) blocks, host side."""
+    lib = _lib.load()
+    src = np.frombuffer(bytes(data), np.uint8).copy()
+    out = np.zeros(lib.ofdm_rs255_encoded_len(src.size), np.uint8)
+    _check(lib, lib.ofdm_rs255_encode(src.ctypes.data if src.size else None, src.size, out.ctypes.data), "ofdm_rs255_encode")
+    return bytes(out)
+
+
+def decipher_transmission_bytes(code: bytes) -> Optional[bytes]:
+    """utils::decipher_transmission_bytes (src/utils.rs:150-180): None where the reference returns None
+    (a block with more than 16 byte errors)."""
+    lib = _lib.load()
+    src = np.frombuffer(bytes(code), np.uint8).copy()
+    out = np.zeros(lib.ofdm_rs255_decoded_len(src.size), np.uint8)
+    rc = lib.ofdm_rs255_decode(src.ctypes.data if src.size else None, src.size, out.ctypes.data, None)
+    if rc == -6:
+        return None
+    _check(lib, rc, "ofdm_rs255_decode")
+    return bytes(out)
+
+
 def locking_signal(length: int = 80) -> np.ndarray:
     """src/transmitter.rs:60-72 (host-side constant; the library builds the same table into its frame header)."""
     v = 0.5 * (np.arange(length) / (2.0 * length) + 0.5)

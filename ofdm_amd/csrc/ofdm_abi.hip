@@ -125,6 +125,7 @@ const char *ofdm_strerror(int status) {
     case OFDM_ERR_NO_DEVICE: return "no usable HIP device";
     case OFDM_ERR_HIP: return "HIP runtime error";
     case OFDM_ERR_NOMEM: return "out of device memory";
+    case OFDM_ERR_UNCORRECTABLE: return "uncorrectable Reed-Solomon block";
     default: return "unknown status";
     }
 }

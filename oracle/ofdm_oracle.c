@@ -293,6 +293,130 @@ void orc_stdrng_training(int len, oc64 *out) {
     }
 }
 
+/* ------------------------------------------------------------------ outer Reed-Solomon framing, utils.rs:97-180
+ * reed-solomon = "0.2.1" (Cargo.toml:35) is not under /root/reference.  Its published construction: GF(2^8) mod
+ * x^8+x^4+x^3+x^2+1 (0x11d), alpha = 2, generator prod_{i<nsym}(x - alpha^i), code word = message then remainder.
+ * Encoder pinned by the published "Reed-Solomon codes for coders" vectors (tests).  The decoder here solves the key
+ * equation with the extended Euclidean algorithm (the library uses Berlekamp-Massey): two routes to the same unique
+ * answer for <= nsym/2 errors. */
+static uint8_t rs_exp[512], rs_log[256];
+static void rs_init(void) {
+    if (rs_exp[0]) return;
+    int x = 1;
+    for (int i = 0; i < 255; i++) { rs_exp[i] = (uint8_t)x; rs_log[x] = (uint8_t)i; x <<= 1; if (x & 0x100) x ^= 0x11d; }
+    for (int i = 255; i < 512; i++) rs_exp[i] = rs_exp[i - 255];
+}
+static uint8_t rs_mul(uint8_t a, uint8_t b) { return (a && b) ? rs_exp[rs_log[a] + rs_log[b]] : 0; }
+static uint8_t rs_inv(uint8_t a) { return rs_exp[255 - rs_log[a]]; }
+static uint8_t rs_eval_lo(const uint8_t *p, int deg, uint8_t x) { /* p[i] multiplies x^i */
+    uint8_t v = 0;
+    for (int i = deg; i >= 0; i--) v = rs_mul(v, x) ^ p[i];
+    return v;
+}
+int orc_rs_encode(const uint8_t *msg, int n, int nsym, uint8_t *out) { /* out[n + nsym] */
+    rs_init();
+    if (n < 0 || nsym <= 0 || n + nsym > 255) return -1;
+    uint8_t g[256] = {1};
+    int deg = 0;
+    for (int i = 0; i < nsym; i++) { /* highest degree first */
+        uint8_t ng[256] = {0};
+        for (int j = 0; j <= deg; j++) { ng[j] ^= g[j]; ng[j + 1] ^= rs_mul(g[j], rs_exp[i]); }
+        memcpy(g, ng, sizeof g);
+        deg++;
+    }
+    uint8_t buf[256 + 255] = {0};
+    memcpy(buf, msg, (size_t)n);
+    for (int i = 0; i < n; i++) {
+        uint8_t c = buf[i];
+        if (c) for (int j = 1; j <= nsym; j++) buf[i + j] ^= rs_mul(g[j], c);
+    }
+    memcpy(out, msg, (size_t)n);
+    memcpy(out + n, buf + n, (size_t)nsym);
+    return 0;
+}
+static int rs_deg(const uint8_t *p, int maxdeg) { while (maxdeg > 0 && p[maxdeg] == 0) maxdeg--; return maxdeg; }
+/* corrects cw[len] in place (len <= 255); returns corrected count or -1 */
+int orc_rs_correct(uint8_t *cw, int len, int nsym) {
+    rs_init();
+    uint8_t S[64] = {0};
+    int any = 0;
+    for (int i = 0; i < nsym; i++) {
+        uint8_t v = 0;
+        for (int j = 0; j < len; j++) v = rs_mul(v, rs_exp[i]) ^ cw[j];
+        S[i] = v; any |= v;
+    }
+    if (!any) return 0;
+    /* extended Euclid on (x^nsym, S(x)), polynomials lowest degree first */
+    uint8_t r0[80] = {0}, r1[80] = {0}, t0[80] = {0}, t1[80] = {0};
+    r0[nsym] = 1;
+    memcpy(r1, S, (size_t)nsym);
+    t1[0] = 1;
+    int d0 = nsym, d1 = rs_deg(r1, nsym - 1);
+    while (d1 >= nsym / 2 && !(d1 == 0 && r1[0] == 0)) {
+        /* r0 = q r1 + rem ; t2 = t0 - q t1 */
+        uint8_t rem[80], tt[80];
+        memcpy(rem, r0, sizeof rem); memcpy(tt, t0, sizeof tt);
+        int dr = d0;
+        while (dr >= d1 && !(dr == 0 && rem[0] == 0)) {
+            uint8_t c = rs_mul(rem[dr], rs_inv(r1[d1]));
+            int sh = dr - d1;
+            for (int i = 0; i <= d1; i++) rem[i + sh] ^= rs_mul(c, r1[i]);
+            for (int i = 0; i + sh < 80; i++) tt[i + sh] ^= rs_mul(c, t1[i]);
+            dr = rs_deg(rem, dr);
+            if (dr == 0 && rem[0] == 0) break;
+        }
+        memcpy(r0, r1, sizeof r0); memcpy(t0, t1, sizeof t0); d0 = d1;
+        memcpy(r1, rem, sizeof r1); memcpy(t1, tt, sizeof t1); d1 = rs_deg(r1, 79);
+    }
+    if (t1[0] == 0) return -1;
+    uint8_t k = rs_inv(t1[0]), sigma[80], omega[80];
+    for (int i = 0; i < 80; i++) { sigma[i] = rs_mul(t1[i], k); omega[i] = rs_mul(r1[i], k); }
+    int L = rs_deg(sigma, 79);
+    if (L > nsym / 2) return -1;
+    int found = 0;
+    for (int j = 0; j < len; j++) {
+        int lx = len - 1 - j;                 /* X = alpha^lx */
+        uint8_t xi = rs_exp[(255 - lx) % 255]; /* X^-1 */
+        if (rs_eval_lo(sigma, L, xi) != 0) continue;
+        uint8_t den = 0, p = 1;               /* sigma'(X^-1): odd-degree terms */
+        for (int i = 1; i <= L; i += 2) { den ^= rs_mul(sigma[i], p); p = rs_mul(p, rs_mul(xi, xi)); }
+        if (den == 0) return -1;
+        uint8_t mag = rs_mul(rs_exp[lx % 255], rs_mul(rs_eval_lo(omega, nsym - 1, xi), rs_inv(den)));
+        cw[j] ^= mag;
+        found++;
+    }
+    if (found != L) return -1;
+    for (int i = 0; i < nsym; i++) {
+        uint8_t v = 0;
+        for (int j = 0; j < len; j++) v = rs_mul(v, rs_exp[i]) ^ cw[j];
+        if (v) return -1;
+    }
+    return found;
+}
+/* create_transmission_bytes (utils.rs:97-136): out holds 255 * (n / 223 + 1) bytes */
+long orc_create_transmission_bytes(const uint8_t *data, long n, uint8_t *out) {
+    long blocks = n / 223 + 1;
+    for (long b = 0; b < blocks; b++) {
+        uint8_t scratch[223] = {0};
+        long have = n - b * 223;
+        if (have > 0) memcpy(scratch, data + b * 223, (size_t)(have < 223 ? have : 223));
+        orc_rs_encode(scratch, 223, 32, out + b * 255);
+    }
+    return blocks * 255;
+}
+/* decipher_transmission_bytes (utils.rs:150-180): out holds 223 * (n / 255 + 1) bytes; -1 = None */
+long orc_decipher_transmission_bytes(const uint8_t *code, long n, uint8_t *out) {
+    long blocks = n / 255 + 1;
+    for (long b = 0; b < blocks; b++) {
+        uint8_t scratch[255] = {0};
+        long have = n - b * 255;
+        if (have > 0) memcpy(scratch, code + b * 255, (size_t)(have < 255 ? have : 255));
+        if (orc_rs_correct(scratch, 255, 32) < 0) return -1;
+        memcpy(out + b * 223, scratch, 223);
+    }
+    return blocks * 223;
+}
+
 static inline int stream_bit(const uint8_t *bytes, size_t nbytes, size_t bit) {
     size_t by = bit >> 3;
     if (by >= nbytes) return 0;

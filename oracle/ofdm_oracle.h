@@ -66,6 +66,10 @@ void orc_default_preamble(int len, oc64 *out);                  /* transmitter.r
 void orc_default_training(int len, oc64 *out);                  /* transmitter.rs:88-96, SplitMix64 seed 50 */
 void orc_stdrng_preamble(int len, oc64 *out);                   /* transmitter.rs:75-84 with rand 0.8 StdRng restated (unverified) */
 void orc_stdrng_training(int len, oc64 *out);                   /* transmitter.rs:88-96 with rand 0.8 StdRng restated (unverified) */
+int orc_rs_encode(const uint8_t *msg, int n, int nsym, uint8_t *out);   /* reed-solomon 0.2.1 construction (utils.rs:108) */
+int orc_rs_correct(uint8_t *cw, int len, int nsym);
+long orc_create_transmission_bytes(const uint8_t *data, long n, uint8_t *out);   /* utils.rs:97-136 */
+long orc_decipher_transmission_bytes(const uint8_t *code, long n, uint8_t *out); /* utils.rs:150-180 */
 void orc_chacha_keystream_block(const uint32_t in[16], int rounds, uint32_t out[16]); /* pinned by RFC 7539 2.3.2 */
 size_t orc_modulate_count(size_t nbytes, int modulation);
 size_t orc_modulate(const uint8_t *bytes, size_t nbytes, int modulation, oc64 *out); /* transmitter.rs:108-140 + EXT-1 */

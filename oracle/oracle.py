@@ -206,6 +206,35 @@ def stdrng_training(length=64):
     return out
 
 
+def rs_encode(msg: bytes, nsym: int) -> bytes:
+    m = np.frombuffer(bytes(msg), np.uint8).copy()
+    out = np.zeros(m.size + nsym, np.uint8)
+    assert lib().orc_rs_encode(_u8(m), C.c_int(m.size), C.c_int(nsym), _u8(out)) == 0
+    return bytes(out)
+
+
+def rs_correct(cw: bytes, nsym: int):
+    c = np.frombuffer(bytes(cw), np.uint8).copy()
+    n = lib().orc_rs_correct(_u8(c), C.c_int(c.size), C.c_int(nsym))
+    return (bytes(c), n)
+
+
+def create_transmission_bytes(data: bytes) -> bytes:
+    d = np.frombuffer(bytes(data), np.uint8).copy()
+    out = np.zeros(255 * (d.size // 223 + 1), np.uint8)
+    lib().orc_create_transmission_bytes.restype = C.c_long
+    n = lib().orc_create_transmission_bytes(_u8(d) if d.size else None, C.c_long(d.size), _u8(out))
+    return bytes(out[:n])
+
+
+def decipher_transmission_bytes(code: bytes):
+    c = np.frombuffer(bytes(code), np.uint8).copy()
+    out = np.zeros(223 * (c.size // 255 + 1), np.uint8)
+    lib().orc_decipher_transmission_bytes.restype = C.c_long
+    n = lib().orc_decipher_transmission_bytes(_u8(c) if c.size else None, C.c_long(c.size), _u8(out))
+    return None if n < 0 else bytes(out[:n])
+
+
 def chacha_block(state16, rounds):
     st = np.ascontiguousarray(state16, dtype=np.uint32)
     out = np.zeros(16, np.uint32)

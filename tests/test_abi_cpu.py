@@ -114,6 +114,71 @@ def test_stdrng_pilots_two_restatements_agree(lib, orc):
     assert lib.ofdm_stdrng_pilots(100, 25, None, None) == -1
 
 
+# ---- 8(f) rank 4: outer Reed-Solomon(255,223) framing (src/utils.rs:97-180), host side
+def test_rs_encoder_published_vectors(orc):
+    """The reed-solomon 0.2.1 construction (GF(2^8) 0x11d, alpha = 2, roots alpha^0..) is the one of "Reed-Solomon codes
+    for coders"; its two published examples pin the oracle's encoder."""
+    qr = bytes([0x40, 0xD2, 0x75, 0x47, 0x76, 0x17, 0x32, 0x06, 0x27, 0x26, 0x96, 0xC6, 0xC6, 0x96, 0x70, 0xEC])
+    assert orc.rs_encode(qr, 10)[16:].hex() == "bc2a90136bafeffd4be0"
+    assert orc.rs_encode(b"hello world", 10)[11:].hex() == "ed2554c4fdfd89f3a8aa"
+    cw = bytearray(orc.rs_encode(b"hello world", 10))
+    for i, v in ((0, 0x55), (5, 1), (20, 0xFF), (9, 3), (12, 7)):
+        cw[i] ^= v
+    fixed, n = orc.rs_correct(bytes(cw), 10)
+    assert n == 5 and fixed[:11] == b"hello world"
+    cw[1] ^= 9  # six errors > t = 5
+    assert orc.rs_correct(bytes(cw), 10)[1] == -1 or orc.rs_correct(bytes(cw), 10)[0][:11] != b"hello world"
+
+
+def test_rs255_framing_library_vs_oracle(lib, orc):
+    lib.ofdm_rs255_encoded_len.restype = C.c_int64
+    lib.ofdm_rs255_encoded_len.argtypes = [C.c_int64]
+    lib.ofdm_rs255_decoded_len.restype = C.c_int64
+    lib.ofdm_rs255_decoded_len.argtypes = [C.c_int64]
+    lib.ofdm_rs255_encode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ofdm_rs255_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    assert lib.ofdm_rs255_encoded_len(500) == 765  # lab3c: 500 text bytes -> 765 (SURVEY 8c vi)
+    rng = np.random.default_rng(9)
+    for n in (0, 1, 222, 223, 224, 446, 500, 1337):
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        want = orc.create_transmission_bytes(bytes(data))
+        assert len(want) == 255 * (n // 223 + 1)  # a final zero-padded block is always emitted (utils.rs:123-131)
+        got = np.zeros(lib.ofdm_rs255_encoded_len(n), np.uint8)
+        assert lib.ofdm_rs255_encode(data.ctypes.data if n else None, n, got.ctypes.data) == 0
+        assert bytes(got) == want
+        # up to 16 byte errors per block are corrected: Berlekamp-Massey (library) and Euclid (oracle) agree
+        bad = got.copy()
+        total = 0
+        for b in range(got.size // 255):
+            k = int(rng.integers(0, 17))
+            for i in rng.choice(255, k, replace=False):
+                bad[b * 255 + i] ^= int(rng.integers(1, 256))
+            total += k
+        out = np.zeros(lib.ofdm_rs255_decoded_len(bad.size), np.uint8)
+        cor = C.c_int32()
+        assert lib.ofdm_rs255_decode(bad.ctypes.data, bad.size, out.ctypes.data, C.byref(cor)) == 0 and cor.value == total
+        plain = orc.decipher_transmission_bytes(bytes(bad))
+        assert plain == bytes(out) and plain[:n] == bytes(data) and not any(plain[n:])
+        assert len(plain) == 223 * (bad.size // 255 + 1)  # the empty remainder decodes to one more zero block (utils.rs:172-176)
+        # a truncated stream: the zero-padded remainder is (almost surely) not a code word
+        if n >= 223:
+            cut = bytes(bad[: 255 + 40])
+            o2 = np.zeros(lib.ofdm_rs255_decoded_len(len(cut)), np.uint8)
+            b2 = np.frombuffer(cut, np.uint8).copy()
+            assert (lib.ofdm_rs255_decode(b2.ctypes.data, b2.size, o2.ctypes.data, None) == -6) == (orc.decipher_transmission_bytes(cut) is None)
+    # 17 errors in a block: beyond unique decoding -> rejected
+    data = rng.integers(0, 256, 223, dtype=np.uint8)
+    code = np.zeros(510, np.uint8)
+    lib.ofdm_rs255_encode(data.ctypes.data, 223, code.ctypes.data)
+    for i in rng.choice(255, 17, replace=False):
+        code[i] ^= int(rng.integers(1, 256))
+    out = np.zeros(lib.ofdm_rs255_decoded_len(510), np.uint8)
+    assert lib.ofdm_rs255_decode(code.ctypes.data, 510, out.ctypes.data, None) == -6
+    lib.ofdm_strerror.restype = C.c_char_p
+    assert lib.ofdm_strerror(-6) == b"uncorrectable Reed-Solomon block"
+    assert lib.ofdm_rs255_encode(None, 5, out.ctypes.data) == -1
+
+
 def test_create_rejects_bad_params_and_missing_gpu(lib):
     from ofdm_amd import Params
 

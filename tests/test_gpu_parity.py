@@ -411,6 +411,27 @@ def test_stdrng_pilot_tables(api, orc):
     assert bytes(orc.decode_sc(wide(cap), guard=True, modulation=orc.QAM64, training=trn)["bytes"]) == pay
 
 
+def test_outer_rs_over_the_link(api, orc):
+    """8(f) rank 4 / lab3c wiring: text -> create_transmission_bytes -> encode -> channel -> decode ->
+    decipher_transmission_bytes (src/utils.rs:97-180, examples/lab3c.rs:15-54), with two OFDM symbols blanked on the air:
+    12 consecutive wrong-ish bytes inside one 255-byte block, which RS(255,223) repairs."""
+    rng = np.random.default_rng(12)
+    text = bytes(rng.integers(32, 127, 500, dtype=np.uint8))
+    coded = api.create_transmission_bytes(text)
+    assert len(coded) == 765 and coded == orc.create_transmission_bytes(text)
+    tx = api.encode(coded, True, api.BPSK)
+    assert tx.size == 800 + 80 * 131  # SURVEY 8c (vi): 765 B BPSK/guard -> 131 data symbols
+    cap = wide(through_channel(orc, rng, tx, tx.size + 200, 40, 0.002, snr_db=30.0, data_start=800))
+    start = 40 + 9 + 800 + 80 * 20
+    cap[start:start + 160] = 0
+    got = api.decode(cap, True, api.BPSK)
+    assert len(got) == 765 and got != coded
+    plain = api.decipher_transmission_bytes(got)
+    assert plain is not None and plain[:500] == text == orc.decipher_transmission_bytes(got)[:500]
+    cap[start:start + 80 * 8] = 0  # 48 bytes gone: beyond 16 per block -> None, like the reference
+    assert api.decipher_transmission_bytes(api.decode(cap, True, api.BPSK)) is None
+
+
 def test_large_batch_properties(api, orc):
     """Properties that need no oracle run, at sizes far beyond what the oracle finishes in seconds:
     TX -> RX round trip is the identity on bytes, two independent kernels (wave-centric fast path and the generic
@@ -494,7 +515,8 @@ def test_cpp_host_loopback(ofdm):
                            os.path.join(root, "tools", "ofdm_loopback.cpp"), "-L", os.path.join(root, "ofdm_amd"), "-lofdm_hip",
                            "-Wl,-rpath," + os.path.join(root, "ofdm_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
     for args in ([], ["--timing-error"], ["--guard", "--qam64", "--bytes", "560", "--timing-error"],
-                 ["--pilots", "stdrng", "--timing-error"]):
+                 ["--pilots", "stdrng", "--timing-error"],
+                 ["--ecc", "--bpsk", "--guard", "--bytes", "500", "--timing-error"]):   # lab3c: 500 B text -> RS -> 765 B
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, (args, r.stdout, r.stderr)          # exit 0 <=> Analysis.num_errs == 0
         assert "num_errs: 0" in r.stdout and "I met a traveller" in r.stdout

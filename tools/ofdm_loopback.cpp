@@ -66,13 +66,15 @@ static bool read_fc32(const char *path, std::vector<Complex64> &x, long start, l
 int main(int argc, char **argv) {
     const char *corpus = "I met a traveller from an antique land, Who said: Two vast and trunkless legs of stone Stand in the desert. ";
     size_t num_bytes = 400;
-    bool guard_bands = false, timing_error = false;
+    bool guard_bands = false, timing_error = false, ecc = false; // ecc: lab3c's ecc_enabled (outer RS(255,223), utils.rs:97-180)
     ModulationScheme modulation = ModulationScheme::Qpsk;
     const char *tx_file = nullptr, *rx_file = nullptr; // examples/lab3c.rs: --transmit f / --receive f [--start a --stop b]
     long start = 0, stop = -1;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--timing-error")) timing_error = true;          // lab3b
         else if (!std::strcmp(argv[i], "--guard")) guard_bands = true;
+        else if (!std::strcmp(argv[i], "--ecc")) ecc = true;
+        else if (!std::strcmp(argv[i], "--bpsk")) modulation = ModulationScheme::Bpsk;
         else if (!std::strcmp(argv[i], "--qam64")) modulation = ModulationScheme::Qam64;
         else if (!std::strcmp(argv[i], "--bytes") && i + 1 < argc) num_bytes = (size_t)std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "--transmit") && i + 1 < argc) tx_file = argv[++i];
@@ -85,13 +87,22 @@ int main(int argc, char **argv) {
     try {
         std::vector<uint8_t> source(num_bytes);
         for (size_t i = 0; i < num_bytes; ++i) source[i] = (uint8_t)corpus[i % std::strlen(corpus)]; // create_transmission_text
+        const std::vector<uint8_t> text = source;
+        if (ecc) source = create_transmission_bytes(source);                       // create_transmission_text(num_bytes, true)
+        auto finish = [&](std::vector<uint8_t> got) -> std::vector<uint8_t> {      // decipher_transmission_text
+            if (!ecc) return got;
+            auto plain = decipher_transmission_bytes(got);
+            if (!plain) { std::printf("outer code: uncorrectable block\n"); return {}; }
+            plain->resize(std::min(plain->size(), text.size()));
+            return *plain;
+        };
         if (rx_file) { // decode a stored capture (or a slice of it)
             std::vector<Complex64> cap;
             if (!read_fc32(rx_file, cap, start, stop)) { std::printf("cannot read %s\n", rx_file); return 4; }
-            auto received = decode(std::move(cap), guard_bands, modulation);
+            auto received = finish(decode(std::move(cap), guard_bands, modulation));
             std::printf("received %zu bytes\n%.*s\n", received.size(), (int)std::min<size_t>(received.size(), 100), (const char *)received.data());
-            if (received.size() != source.size()) return 2;
-            return Analysis(source, received).num_errs == 0 ? 0 : 1;
+            if (received.size() != text.size()) return 2;
+            return Analysis(text, received).num_errs == 0 ? 0 : 1;
         }
         auto tx = encode(source, guard_bands, modulation);                         // ofdm::encode!
         if (tx_file) { // write the frame for tx_samples_from_file
@@ -101,9 +112,9 @@ int main(int argc, char **argv) {
         }
         double fd = 0;
         auto rx = channel(tx, 30.0, timing_error, 2021, &fd);                      // ofdm::channel!(snr: 30.0[, timing_error])
-        auto received = decode(std::move(rx), guard_bands, modulation);            // ofdm::decode!
-        if (received.size() != source.size()) { std::printf("length mismatch: %zu vs %zu\n", received.size(), source.size()); return 2; }
-        Analysis a(source, received);
+        auto received = finish(decode(std::move(rx), guard_bands, modulation));    // ofdm::decode!
+        if (received.size() != text.size()) { std::printf("length mismatch: %zu vs %zu\n", received.size(), text.size()); return 2; }
+        Analysis a(text, received);
         std::printf("Analysis { num_errs: %u, num_block_errs: %u, err_rate: %g }  samples: %zu  f_delta: %g\n", a.num_errs,
                     a.num_block_errs, a.err_rate, tx.size(), fd);
         std::printf("%.*s\n", (int)std::min<size_t>(received.size(), 100), (const char *)received.data());
