@@ -242,11 +242,25 @@ __global__ __launch_bounds__(256) void k_rx_finish(const uint8_t *raw, long long
     const uint8_t *src = raw + f * raw_stride;
     const long long body = (long long)nsym[f] * bytes_per_symbol - 16;
     unsigned long long lo = 0, hi = 0; // bincode fixint little-endian u128 (src/packets/mod.rs:20-32)
-    for (int i = 0; i < 8; ++i) { lo |= (unsigned long long)src[i] << (8 * i); hi |= (unsigned long long)src[8 + i] << (8 * i); }
+    if (((uintptr_t)src & 3) == 0) {
+        const uint32_t *h4 = reinterpret_cast<const uint32_t *>(src);
+        lo = (unsigned long long)h4[0] | ((unsigned long long)h4[1] << 32);
+        hi = (unsigned long long)h4[2] | ((unsigned long long)h4[3] << 32);
+    } else {
+        for (int i = 0; i < 8; ++i) { lo |= (unsigned long long)src[i] << (8 * i); hi |= (unsigned long long)src[8 + i] << (8 * i); }
+    }
     const long long keep = (hi == 0 && lo < (unsigned long long)body) ? (long long)lo : body; // Vec::truncate
     uint8_t *dst = out + f * out_stride;
     if (!ecc) {
-        for (long long i = lane; i < keep; i += 64) dst[i] = src[16 + i];
+        if ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0) { // dword copy (the library's own buffers are 4-byte aligned)
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src + 16);
+            uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+            const long long nd = keep >> 2;
+            for (long long i = lane; i < nd; i += 64) d4[i] = s4[i];
+            for (long long i = (nd << 2) + lane; i < keep; i += 64) dst[i] = src[16 + i];
+        } else {
+            for (long long i = lane; i < keep; i += 64) dst[i] = src[16 + i];
+        }
         if (lane == 0) out_len[f] = (int32_t)keep;
     } else {
         unsigned fixed = 0;
