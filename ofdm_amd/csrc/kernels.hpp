@@ -57,6 +57,8 @@ struct Fast64Params {
 hipError_t run_demod64_fast(const SymParams &p, hipStream_t st, int num_cu);
 // fused estimate_channel + per-symbol demod for N = 64 frames with per-frame offset / CFO / live-symbol count
 hipError_t run_rxframe64(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu);
+// fused encode for N = 64 (map + IFFT + CP + header + normalise, one HBM pass); hipErrorNotSupported outside its envelope
+hipError_t run_txframe64(const SymParams &p, const float2 *header, float header_max, hipStream_t st, int num_cu);
 
 hipError_t run_fft(int n, const SymParams &p, bool inverse, hipStream_t st, int num_cu);
 hipError_t run_ifft_cp(int n, const SymParams &p, hipStream_t st, int num_cu);

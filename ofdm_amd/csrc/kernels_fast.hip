@@ -12,6 +12,7 @@
 // Roofline: HBM -- 640 algorithmic bytes read per symbol (512 actually fetched) + packed bytes written.
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include <stdlib.h>
 
 extern "C" __device__ float __ocml_atan2pi_f32(float, float); // atan2(y, x) / pi (ROCm device library)
 
@@ -305,6 +306,206 @@ hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, in
     case 1: if (!sp.guard) return launch_rxframe<1>(p, false, grid, st); return hipErrorNotSupported;
     default: return hipErrorNotSupported;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_txframe64: encode (src/transmitter.rs:11-58) for N = 64, one 256-thread workgroup per frame, ONE pass over HBM.
+//   The data symbols are built in LDS (D x 80 samples): per group of 8 symbols a wavefront maps the byte stream to
+//   constellation points straight into the Stockham input pattern (modulate + encode_block, transmitter.rs:108-165),
+//   runs the inverse FFT64 in the k_demod64 layout (the symbol's own LDS slot doubles as the transpose slab), adds the
+//   cyclic prefix (prefix_block, transmitter.rs:168-181) and tracks max(re, im).  After one barrier the workgroup knows
+//   the frame's signed maximum (normalize, transmitter.rs:183-194, the constant header's maximum comes from the host)
+//   and streams [header | data] / max to HBM with 16-byte stores.  HBM traffic: payload in, frame out, nothing else
+//   (the two-kernel path wrote the frame, read it back and wrote it again).
+struct TxFrame64Params {
+    const uint8_t *payload;
+    long long payload_stride;
+    const int32_t *payload_len;
+    int payload_bytes;
+    long long n_frames;
+    int n_sym;                 // data symbols per frame
+    const float2 *tw;          // exp(-2 pi i m / 64)
+    const float2 *header;      // 10 constant blocks (800 samples), unnormalised
+    float header_max;
+    float2 *out;
+    long long out_stride;      // samples
+    int debug;                 // OFDM_TX_DEBUG=1: the first two samples of every frame carry section times (s_memtime ticks)
+};
+
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight (__syncthreads() also drains vmcnt, which
+// would turn the next frame's payload prefetch into a stall).
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int BPS, bool GUARD>
+__global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
+    constexpr int S = 80, CP = 16, HDR = 10 * S;
+    constexpr int ND = GUARD ? 48 : 64;
+    constexpr int SYM_BITS = ND * BPS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf *hd = reinterpret_cast<cf *>(smem);                      // [800] the constant header, staged once
+    cf *fb = hd + HDR;                                          // [ceil8(n_sym) * 80] data symbols, unnormalised
+    const int groups = (p.n_sym + 7) >> 3;
+    unsigned *mxw = reinterpret_cast<unsigned *>(fb + (size_t)groups * 8 * S); // frame maximum (float bits, >= 0)
+    unsigned *sbw = mxw + 4;                                                   // the frame's byte stream, as dwords
+    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
+    const int stream_dw = groups * 8 * (SYM_BITS / 8) / 4 + 1;  // dwords the mapper may touch (one dword of slack)
+
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x, nwaves = nthr >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane >> 3, t = lane & 7;
+    cf w[7];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { const cf x = p.tw[r * t]; w[r - 1] = make_float2(x.x, -x.y); } // conjugate: inverse transform
+    int qoff[8]; // bit offset of bin (t + 8m)'s field inside one symbol's stream, -1 = null, -2 = pilot
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int c = t + 8 * m, cls = carrier_class64(c, GUARD);
+        qoff[m] = cls == 0 ? (GUARD ? data_classes_below64(c) : c) * BPS : (cls == 2 ? -2 : -1);
+    }
+    const int wr = swz(8 * t);
+    for (int i = tid; i < HDR; i += nthr) hd[i] = p.header[i];
+
+    // The byte stream = 16-byte little-endian length (src/packets/mod.rs:20-32) + payload + zeros.  Dword i of the
+    // PAYLOAD is fetched by thread (i mod nthr); the first two per thread are prefetched one frame ahead.
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.payload) | (uintptr_t)p.payload_stride) & 3) == 0;
+    auto pay_dword = [&](const uint8_t *pay, long long len, int i) -> unsigned { // payload bytes 4i .. 4i+3, zero past len
+        const long long b0 = 4LL * i;
+        if (b0 + 4 <= len && aligned) return reinterpret_cast<const unsigned *>(pay)[i];
+        unsigned v = 0;
+        for (int j = 0; j < 4; ++j) if (b0 + j < len) v |= (unsigned)pay[b0 + j] << (8 * j);
+        return v;
+    };
+    long long f = blockIdx.x;
+    unsigned pre0 = 0, pre1 = 0;
+    if (f < p.n_frames) {
+        const long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+        const uint8_t *pay = p.payload + f * p.payload_stride;
+        pre0 = pay_dword(pay, len, tid); pre1 = pay_dword(pay, len, tid + nthr);
+    }
+    for (; f < p.n_frames; f += gridDim.x) {
+        lds_only_barrier(); // the previous frame has left LDS (and the header is staged)
+        const long long t0 = p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+        const uint8_t *pay = p.payload + f * p.payload_stride;
+        if (tid < 4) sbw[tid] = tid < 2 ? (unsigned)((unsigned long long)len >> (32 * tid)) : 0u;
+        if (tid + 4 < stream_dw) sbw[4 + tid] = pre0;
+        if (tid + nthr + 4 < stream_dw) sbw[4 + tid + nthr] = pre1;
+        for (int i = tid + 2 * nthr; i + 4 < stream_dw; i += nthr) sbw[4 + i] = pay_dword(pay, len, i); // long payloads
+        if (tid == 0) *mxw = 0u;
+        {   // next frame's payload: in flight while this frame is built and written
+            const long long fn = f + gridDim.x;
+            if (fn < p.n_frames) {
+                const long long ln = p.payload_len ? p.payload_len[fn] : p.payload_bytes;
+                const uint8_t *pn = p.payload + fn * p.payload_stride;
+                pre0 = pay_dword(pn, ln, tid); pre1 = pay_dword(pn, ln, tid + nthr);
+            }
+        }
+        lds_only_barrier();
+        const long long t1 = p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const int npoints = (int)(((16 + len) * 8 + BPS - 1) / BPS); // points that carry stream bits; the rest are 0
+        float lmax = 0.f;
+        for (int g = wave; g < groups; g += nwaves) {
+            const int k = 8 * g + s;       // this lane's symbol
+            cf *buf = fb + k * S;          // its LDS slot (80 >= 72 entries: also the transpose slab)
+            cf v[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                cf z = make_float2(0.f, 0.f);
+                if (qoff[m] == -2) z = make_float2(1.f, 0.f);
+                else if (qoff[m] >= 0) {
+                    const int bit = k * SYM_BITS + qoff[m];
+                    if (bit < npoints * BPS && k < p.n_sym) {
+                        const unsigned two = (unsigned)sb[bit >> 3] | ((unsigned)sb[(bit >> 3) + 1] << 8);
+                        z = map_point((two >> (bit & 7)) & ((1u << BPS) - 1u), BPS);
+                    }
+                }
+                v[m] = z;
+            }
+            bfly8<true>(v);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+            bfly8<true>(v);
+            // v[q] = 64 x[t + 8q]; prefix_block: out = [x[48..64), x[0..64)]
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const cf y = make_float2(v[q].x * (1.0f / 64), v[q].y * (1.0f / 64));
+                v[q] = y;
+                lmax = fmaxf(lmax, fmaxf(y.x, y.y));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the slab reads above precede the overwrites below
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                buf[CP + t + 8 * q] = v[q];
+                if (q >= 6) buf[t + 8 * q - 48] = v[q];
+            }
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, sh, 64));
+        if (lane == 0) atomicMax(mxw, __float_as_uint(lmax)); // non-negative floats order like their bit patterns
+        lds_only_barrier();
+        const long long t2 = p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const float inv = 1.0f / fmaxf(p.header_max, __uint_as_float(*mxw)); // one divide per thread, then multiplies (<= 1 ulp)
+        // stream [header | data] out: header and data are contiguous in LDS, two samples per 16-byte store
+        const int total2 = (HDR + p.n_sym * S) >> 1;
+        float4 *dst = reinterpret_cast<float4 *>(p.out + f * p.out_stride);
+        const float4 *src4 = reinterpret_cast<const float4 *>(hd);
+        int i = tid;
+        for (; i + 3 * nthr < total2; i += 4 * nthr) {
+            const float4 a = src4[i], b = src4[i + nthr], c = src4[i + 2 * nthr], d = src4[i + 3 * nthr];
+            dst[i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+            dst[i + nthr] = make_float4(b.x * inv, b.y * inv, b.z * inv, b.w * inv);
+            dst[i + 2 * nthr] = make_float4(c.x * inv, c.y * inv, c.z * inv, c.w * inv);
+            dst[i + 3 * nthr] = make_float4(d.x * inv, d.y * inv, d.z * inv, d.w * inv);
+        }
+        for (; i < total2; i += nthr) { const float4 a = src4[i]; dst[i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv); }
+        if (p.debug) {
+            __syncthreads();
+            if (tid == 0) {
+                const long long t3 = (long long)__builtin_amdgcn_s_memtime();
+                dst[0] = make_float4((float)(t1 - t0), (float)(t2 - t1), (float)(t3 - t2), 0.f);
+            }
+        }
+    }
+}
+
+template <int BPS> static hipError_t launch_txframe(const TxFrame64Params &p, bool guard, dim3 grid, size_t lds, hipStream_t st) {
+    const int groups = (p.n_sym + 7) / 8;
+    const dim3 block(64u * (unsigned)(groups < 4 ? groups : 4)); // one wavefront per 8-symbol group, at most four
+    if (guard) hipLaunchKernelGGL((k_txframe64<BPS, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((k_txframe64<BPS, false>), grid, block, lds, st, p);
+    return hipGetLastError();
+}
+// Fused TX for N = 64 frames of up to 56 data symbols.  hipErrorNotSupported => caller uses k_sym<M_TX> + k_tx_finish.
+hipError_t run_txframe64(const SymParams &sp, const float2 *header, float header_max, hipStream_t st, int num_cu) {
+    const int n_sym = sp.syms_per_frame;
+    if (n_sym <= 0 || n_sym > 56 || !sp.payload && sp.payload_bytes) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(sp.out) & 15) || (sp.out_stride_s & 1)) return hipErrorNotSupported; // 16-byte stores
+    if (sp.n_frames <= 0) return hipSuccess;
+    TxFrame64Params p;
+    p.payload = sp.payload; p.payload_stride = sp.payload_stride; p.payload_len = sp.payload_len; p.payload_bytes = sp.payload_bytes;
+    p.n_frames = sp.n_frames; p.n_sym = n_sym; p.tw = sp.tw; p.header = header; p.header_max = header_max;
+    p.out = sp.out; p.out_stride = sp.out_stride_s;
+    { const char *v = getenv("OFDM_TX_DEBUG"); p.debug = v ? atoi(v) : 0; }
+    const int groups = (n_sym + 7) / 8;
+    const size_t lds = (size_t)(800 + groups * 8 * 80) * sizeof(float2) + 16 + (size_t)groups * 8 * 64 + 32; // header + frame + max + byte stream
+    long long per_cu = (long long)(160 * 1024) / (long long)lds;
+    static const int waves_per_cu = [] { const char *v = getenv("OFDM_TX_WAVES"); return v ? atoi(v) : 16; }(); // tuning knob (measured best: 16)
+    const long long wave_cap = waves_per_cu / (groups < 4 ? groups : 4); // wavefronts per CU
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    long long grid = (long long)num_cu * per_cu;
+    if (grid > sp.n_frames) grid = sp.n_frames;
+    switch (sp.bps) {
+    case 1: return launch_txframe<1>(p, sp.guard != 0, dim3((unsigned)grid), lds, st);
+    case 2: return launch_txframe<2>(p, sp.guard != 0, dim3((unsigned)grid), lds, st);
+    case 4: return launch_txframe<4>(p, sp.guard != 0, dim3((unsigned)grid), lds, st);
+    case 6: return launch_txframe<6>(p, sp.guard != 0, dim3((unsigned)grid), lds, st);
+    case 8: return launch_txframe<8>(p, sp.guard != 0, dim3((unsigned)grid), lds, st);
+    }
+    return hipErrorNotSupported;
 }
 
 template <int BPS> static hipError_t launch_bps(const Fast64Params &p, bool guard, dim3 grid, hipStream_t st) {

@@ -608,14 +608,20 @@ int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, 
         src = (const uint8_t *)cw; src_stride = coded; src_len = payload_len ? (const int32_t *)cl : nullptr;
         src_bytes = (int32_t)coded;
     }
+    SymParams p = base_params(c);
+    p.n_frames = n_frames; p.syms_per_frame = (int)ofdm_data_symbols(c, payload_bytes);
+    p.payload = src; p.payload_stride = src_stride; p.payload_len = src_len; p.payload_bytes = src_bytes;
+    p.out = reinterpret_cast<float2 *>(out); p.out_stride_s = out_stride;
+    if (c->prm.n_fft == 64) { // one workgroup per frame, frame built in LDS, single pass over HBM
+        hipError_t fe = run_txframe64(p, c->d_header, c->header_max, c->stream, c->num_cu);
+        if (fe == hipSuccess) return OFDM_OK;
+        if (fe != hipErrorNotSupported) { c->last_hip = (int)fe; return OFDM_ERR_HIP; }
+    }
     void *mx;
     int rc = ws_get(c, 0, sizeof(unsigned) * (size_t)n_frames, &mx);
     if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(mx, 0, sizeof(unsigned) * (size_t)n_frames, c->stream));
-    SymParams p = base_params(c);
-    p.n_frames = n_frames; p.syms_per_frame = (int)ofdm_data_symbols(c, payload_bytes);
-    p.payload = src; p.payload_stride = src_stride; p.payload_len = src_len; p.payload_bytes = src_bytes;
-    p.out = reinterpret_cast<float2 *>(out); p.out_stride_s = out_stride; p.frame_max = (unsigned *)mx;
+    p.frame_max = (unsigned *)mx;
     HIP_TRY(c, run_tx_symbols(c->prm.n_fft, p, c->stream, c->num_cu));
     HIP_TRY(c, run_tx_finish(reinterpret_cast<float2 *>(out), n_frames, out_stride, 10 * S, frame, c->d_header,
                              c->header_max, (const unsigned *)mx, c->stream));
