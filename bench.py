@@ -25,7 +25,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (BASELINE config 2: 1M)")
     ap.add_argument("--snr-db", type=float, default=30.0)
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")

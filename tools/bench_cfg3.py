@@ -81,6 +81,17 @@ def run(api, torch, n_frames, steps, device):
         "full_chain_hbm_frac_of_one_read": chain_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
         "frames_decoded": nok, "ber_decoded_frames": bits / max(1, nok * 560 * 8),
     }
+    # --- TX side of the hot path: encode (modulate + encode_block + IFFT + CP + header + normalise) for the same payloads
+    npay = min(n_frames, 131072)
+    txo = ctx.encode_batch(payload[:npay])
+    torch.cuda.synchronize()
+    ctx.timer_start()
+    for _ in range(steps):
+        ctx.encode_batch(payload[:npay], out=txo)
+    tms = ctx.timer_stop_ms() / steps
+    out["tx_encode"] = {"kernel": "k_txframe64<6, true>", "frames": npay, "ms": tms, "msamples_per_s": npay * txo.shape[-1] / tms / 1e3,
+                        "hbm_frac_of_one_write": npay * txo.shape[-1] * 8 / (tms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    del txo
     # --- Schmidl-Cox kernel alone
     ctx.sc_correlate(x)
     torch.cuda.synchronize()
