@@ -423,6 +423,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
     auto to_slow = [&](long long fr) { p.d_hat[fr] = -1; p.slow_list[atomicAdd(p.slow_count, 1)] = (int32_t)fr; };
 
     for (int i = nstaged + tid; i < ns + L; i += WG) raw[i] = make_float2(0.f, 0.f); // never written by the DMA
+    if (tid == 0) { bq[NCH] = make_float2(0.f, 0.f); be[NCH] = 0.f; } // chunk NCH: local prefix 0 of the wavefront after the last
     long long f = blockIdx.x;
     const long long fstep = gridDim.x;
     if (f < p.n_frames) stage(f);
@@ -434,48 +435,38 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
         lds_barrier();                                   // B0: ... and everyone else's
         const long long t1 = p.debug >= 10 ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const bool more = f + fstep < p.n_frames;
-        // ---- phase 1 (f32): chunk totals of q and e, scanned per virtual wavefront
-        float tqr[CPT], tqi[CPT], te[CPT], iqr[CPT], iqi[CPT], ie[CPT];
+        // ---- phase 1 (f32): chunk totals of q and e; exclusive prefixes WITHIN each virtual wavefront (64 chunks) go to
+        //      LDS together with the wavefront totals.  A prefix difference that crosses into the next virtual wavefront
+        //      just adds the first one's total, so no second scan across wavefronts (and no barrier for it) is needed.
+        float te[CPT], lqr[CPT], lqi[CPT], le[CPT], Tqr[CPT], Tqi[CPT], Te[CPT];
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
-            const int n0 = (u * WG + tid) * C;
-            tqr[u] = 0.f; tqi[u] = 0.f; te[u] = 0.f;
+            const int vt = u * WG + tid, n0 = vt * C;
+            float tqr = 0.f, tqi = 0.f;
+            te[u] = 0.f;
             if (n0 < ns) {
                 const float4 *pa = reinterpret_cast<const float4 *>(raw + n0), *pb = reinterpret_cast<const float4 *>(raw + n0 + L);
 #pragma unroll
                 for (int i = 0; i < C / 2; ++i) {
                     const float4 x = pa[i], y = pb[i];
-                    tqr[u] += x.x * y.x + x.y * y.y; tqi[u] += x.x * y.y - x.y * y.x; te[u] += x.x * x.x + x.y * x.y;
-                    tqr[u] += x.z * y.z + x.w * y.w; tqi[u] += x.z * y.w - x.w * y.z; te[u] += x.z * x.z + x.w * x.w;
+                    tqr += x.x * y.x + x.y * y.y; tqi += x.x * y.y - x.y * y.x; te[u] += x.x * x.x + x.y * x.y;
+                    tqr += x.z * y.z + x.w * y.w; tqi += x.z * y.w - x.w * y.z; te[u] += x.z * x.z + x.w * x.w;
                 }
             }
-            tes[u * WG + tid] = te[u];
-            iqr[u] = wave_scan_f(tqr[u]); iqi[u] = wave_scan_f(tqi[u]); ie[u] = wave_scan_f(te[u]);
-            if (lane == 63) { const int vw = u * NW + wave; wtot[vw * 4 + 0] = iqr[u]; wtot[vw * 4 + 1] = iqi[u]; wtot[vw * 4 + 2] = ie[u]; }
+            const float iqr = wave_scan_f(tqr), iqi = wave_scan_f(tqi), ie = wave_scan_f(te[u]);
+            lqr[u] = iqr - tqr; lqi[u] = iqi - tqi; le[u] = ie - te[u];
+            Tqr[u] = readlane_f(iqr, 63); Tqi[u] = readlane_f(iqi, 63); Te[u] = readlane_f(ie, 63);
+            tes[vt] = te[u];
+            bq[vt] = make_float2(lqr[u], lqi[u]);
+            be[vt] = le[u];
+            if (lane == 63) { const int vw = u * NW + wave; wtot[vw * 4 + 0] = iqr; wtot[vw * 4 + 1] = iqi; wtot[vw * 4 + 2] = ie; }
         }
-        lds_barrier(); // B2: virtual-wave totals visible
-        const long long t2 = p.debug >= 10 ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        float mybqr[CPT], mybqi[CPT], mybe[CPT];
-        {
-            float wq = lane < VW ? wtot[lane * 4 + 0] : 0.f, wi = lane < VW ? wtot[lane * 4 + 1] : 0.f,
-                  we = lane < VW ? wtot[lane * 4 + 2] : 0.f;
-            float sq = wq, si = wi, se = we;
-            sq += dpp_s<0x111, 0xF>(sq); si += dpp_s<0x111, 0xF>(si); se += dpp_s<0x111, 0xF>(se);
-            sq += dpp_s<0x112, 0xF>(sq); si += dpp_s<0x112, 0xF>(si); se += dpp_s<0x112, 0xF>(se);
-#pragma unroll
-            for (int u = 0; u < CPT; ++u) {
-                const int vw = u * NW + wave, vt = u * WG + tid;
-                mybqr[u] = (iqr[u] - tqr[u]) + (readlane_f(sq, vw) - readlane_f(wq, vw));
-                mybqi[u] = (iqi[u] - tqi[u]) + (readlane_f(si, vw) - readlane_f(wi, vw));
-                mybe[u] = (ie[u] - te[u]) + (readlane_f(se, vw) - readlane_f(we, vw));
-                bq[vt] = make_float2(mybqr[u], mybqi[u]);
-                be[vt] = mybe[u];
-                if (vt == NCH - 1) { bq[NCH] = make_float2(mybqr[u] + tqr[u], mybqi[u] + tqi[u]); be[NCH] = mybe[u] + te[u]; } // a backward slide may start here
-            }
-        }
-        lds_barrier(); // B3: chunk prefixes visible
-        const long long t3 = p.debug >= 10 ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        lds_barrier(); // B3: chunk prefixes, energies and wavefront totals visible
+        const long long t2 = t1, t3 = p.debug >= 10 ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (p.debug == 2) { lds_barrier(); if (more) stage(f + fstep); continue; }
+        float etot = 0.f; // frame energy: bounds every prefix (error margin of the coarse bound)
+#pragma unroll
+        for (int w = 0; w < VW; ++w) etot += wtot[w * 4 + 2];
 
         // ---- coarse pass: can any of a chunk's 10 lags reach the threshold?
 #pragma unroll
@@ -483,12 +474,13 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
             const int vt = u * WG + tid;
             bool flag = false;
             if (vt * C < n) { // owns at least one searched lag (implies vt + cW + cL < NCH)
+                const bool xW = lane + cW >= 64, xL = lane + cL >= 64, xWL = lane + cW + cL >= 64; // leaves this virtual wavefront
                 const float2 b1 = bq[vt + cW];
-                const float Pr = b1.x - mybqr[u], Pi = b1.y - mybqi[u];
+                const float Pr = (b1.x - lqr[u]) + (xW ? Tqr[u] : 0.f), Pi = (b1.y - lqi[u]) + (xW ? Tqi[u] : 0.f);
                 const float eL = tes[vt + cL], eW = tes[vt + cW], eWL = tes[vt + cW + cL];
-                const float btop = be[vt + cW + cL];
-                const float E0 = be[vt + cW] - mybe[u], R0 = btop - be[vt + cL];
-                const float dlt = (btop + eWL) * 4e-6f;                       // f32 error of a prefix difference
+                const float E0 = (be[vt + cW] - le[u]) + (xW ? Te[u] : 0.f);
+                const float R0 = (be[vt + cW + cL] - be[vt + cL]) + ((xWL ? Te[u] : 0.f) - (xL ? Te[u] : 0.f));
+                const float dlt = etot * 4e-6f;                                // f32 error of a prefix difference
                 const float ub = __builtin_sqrtf(Pr * Pr + Pi * Pi) * 1.000001f + 0.5f * (te[u] + eL + eW + eWL) + 2.f * dlt;
                 const float Elo = E0 - te[u] - dlt, Rlo = R0 - eL - dlt;
                 flag = ub > 0.f && !(Elo > 0.f && Rlo > 0.f && ub * ub < thr_c * Elo * Rlo);
@@ -541,15 +533,20 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                     const int cb = c + hh;
                     // every LDS read of the slide up front: one round trip
                     const float2 q0 = bq[cb], q1 = bq[cb + cW];
-                    const float e0 = be[cb], e1 = be[cb + cW], e2 = be[cb + cL], etop = be[cb + cW + cL];
+                    const float e0 = be[cb], e1 = be[cb + cW], e2 = be[cb + cL], e3 = be[cb + cW + cL];
+                    // wave-local prefixes: a difference that leaves its virtual wavefront adds that wavefront's total
+                    const int v0 = cb >> 6, v2 = (cb + cL) >> 6;
+                    const bool xP = ((cb + cW) >> 6) != v0, xR = ((cb + cW + cL) >> 6) != v2;
+                    const float t0r = wtot[v0 * 4 + 0], t0i = wtot[v0 * 4 + 1], t0e = wtot[v0 * 4 + 2], t2e = wtot[v2 * 4 + 2];
+                    const float etop = e3 + t0e + t2e; // magnitude of the terms behind E and R (cancellation bound)
                     cf sa[5], sb[5], sc[5], sd[5];
 #pragma unroll
                     for (int k = 0; k < 5; ++k) { // low sample x of the step to round k's lag (forward k = 0 sits on the boundary: no step)
                         const int x = hh ? m0 + 9 - k : m0 + (k > 0 ? k - 1 : 0);
                         sa[k] = raw[x]; sb[k] = raw[x + L]; sc[k] = raw[x + W]; sd[k] = raw[x + W + L];
                     }
-                    float Pr = q1.x - q0.x, Pi = q1.y - q0.y;
-                    float E = e1 - e0, R = etop - e2;
+                    float Pr = (q1.x - q0.x) + (xP ? t0r : 0.f), Pi = (q1.y - q0.y) + (xP ? t0i : 0.f);
+                    float E = (e1 - e0) + (xP ? t0e : 0.f), R = (e3 - e2) + (xR ? t2e : 0.f);
                     float emin = 3.0e38f, mmax = -1.f;
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {

@@ -7,7 +7,7 @@ from tools import bench_cfg3
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
 x, _ = bench_cfg3.synth(api, torch, ctx, n, 2176)
-names = ["dma_wait", "phase1", "bases", "coarse", "fine", "fine.slide", "fine.select", "fine.exact"]
+names = ["dma_wait", "(unused)", "phase1", "coarse", "fine", "fine.slide", "fine.select", "fine.exact"]
 for k, nm in enumerate(names):
     os.environ["OFDM_SC_DEBUG"] = str(10 + k)
     dh, _, _ = ctx.sc_correlate(x)
