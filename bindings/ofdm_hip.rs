@@ -40,6 +40,7 @@ extern "C" {
     pub fn ofdm_rs255_decoded_len(n_code: i64) -> i64;
     pub fn ofdm_rs255_encode(data: *const u8, n_bytes: i64, out: *mut u8) -> c_int;
     pub fn ofdm_rs255_decode(code: *const u8, n_code: i64, out: *mut u8, corrected: *mut i32) -> c_int;
+    pub fn ofdm_tx_symbols_batch(ctx: *mut ofdm_ctx, bytes_dev: *const u8, n_bytes: i64, out_dev: *mut ofdm_fc32, n_sym: i64) -> c_int;
     pub fn ofdm_chacha_block(key8: *const u32, words12_15: *const u32, rounds: i32, out16: *mut u32) -> c_int;
     pub fn ofdm_create(p: *const ofdm_params, preamble: *const f64, training: *const f64, device: c_int,
                        stream: *mut c_void, out: *mut *mut ofdm_ctx) -> c_int;

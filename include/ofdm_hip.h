@@ -128,6 +128,10 @@ int64_t ofdm_frame_samples(const ofdm_ctx *ctx, int64_t payload_bytes); /* 10*S 
 int ofdm_fft_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, ofdm_fc32 *out_dev, int64_t n_vec, int inverse);
 /* prefix_block (src/transmitter.rs:168-181): n_sym blocks of n_fft bins -> n_sym blocks of n_fft+cp samples */
 int ofdm_ifft_cp_batch(ofdm_ctx *ctx, const ofdm_fc32 *freq_dev, ofdm_fc32 *out_dev, int64_t n_sym);
+/* modulate + encode_block + prefix_block in one pass (src/transmitter.rs:40-53 without the frame header and without
+ * normalize): a continuous byte stream -> n_sym symbols of n_fft+cp samples; n_sym * bytes_per_symbol >= n_bytes, bins
+ * past the end of the stream carry 0 (transmitter.rs:158-160).  Same samples as the three staged calls. */
+int ofdm_tx_symbols_batch(ofdm_ctx *ctx, const uint8_t *bytes_dev, int64_t n_bytes, ofdm_fc32 *out_dev, int64_t n_sym);
 /* unprefix_block (src/receiver.rs:99-104): n_sym blocks of n_fft+cp samples -> n_sym blocks of n_fft bins */
 int ofdm_unprefix_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, ofdm_fc32 *out_dev, int64_t n_sym);
 /* modulate (src/transmitter.rs:108-140) + 16/64/256-QAM: n_bytes -> ceil(8 n_bytes / bps) points */

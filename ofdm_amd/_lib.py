@@ -30,6 +30,7 @@ SIGNATURES = {
     "ofdm_default_pilots": (C.c_int, [i32, i32, vp, vp]),
     "ofdm_stdrng_pilots": (C.c_int, [i32, i32, vp, vp]),
     "ofdm_chacha_block": (C.c_int, [vp, vp, i32, vp]),
+    "ofdm_tx_symbols_batch": (C.c_int, [vp, vp, i64, vp, i64]),
     "ofdm_rs255_encoded_len": (C.c_int64, [i64]),
     "ofdm_rs255_decoded_len": (C.c_int64, [i64]),
     "ofdm_rs255_encode": (C.c_int, [vp, i64, vp]),

@@ -207,6 +207,17 @@ class Context:
         self._ck(self.lib.ofdm_ifft_cp_batch(self.h, _dev(freq), _dev(out), freq.numel() // self.n_fft), "ifft_cp")
         return out
 
+    def tx_symbols(self, data: torch.Tensor, n_sym: Optional[int] = None) -> torch.Tensor:
+        """modulate + encode_block + prefix_block fused (src/transmitter.rs:40-53): a continuous byte stream ->
+        [n_sym, n_fft + cp] samples, identical to the three staged calls."""
+        data = self._u8(data).reshape(-1)
+        nb = data.numel()
+        need = (nb + self.bytes_per_symbol - 1) // self.bytes_per_symbol
+        n_sym = need if n_sym is None else n_sym
+        out = self.empty((n_sym, self.S), torch.complex64)
+        self._ck(self.lib.ofdm_tx_symbols_batch(self.h, _dev(data), nb, _dev(out), n_sym), "tx_symbols")
+        return out
+
     def unprefix_block(self, blocks: torch.Tensor) -> torch.Tensor:
         """unprefix_block (src/receiver.rs:99-104): [..., N+CP] samples -> [..., N] bins."""
         blocks = self._cx(blocks)

@@ -38,6 +38,9 @@ struct SymParams {
     const int32_t *payload_len = nullptr;
     int payload_bytes = 0;
     unsigned *frame_max = nullptr; // per-frame max(0, re, im) as float bits
+    long long tx_raw_total = -1;   // >= 0: TX of a continuous symbol stream (modulate + encode_block + prefix_block only):
+                                   // payload is tx_raw_total plain bytes, one symbol per "frame", no length header, no frame
+                                   // header blocks, no normalise
 };
 
 // N = 64 RX-demod fast path (kernels_fast.hip)

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
     __shared__ cf lds[G * P::LDS_SYM];
     __shared__ unsigned char idx_lds[(MODE == M_DEMOD) ? G * N : 4];
     __shared__ float red[(T > 64) ? G * (T / 64) : 1];
+    __shared__ __align__(4) unsigned char txb[(MODE == M_TX) ? G * (N + 8) : 4]; // TX: the symbol's slice of the byte stream
 
     const int tid = threadIdx.x;
     const int t = tid % T, slot = tid / T;
@@ -85,6 +86,35 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
     constexpr bool PREFETCH = (MODE != M_CHEST && MODE != M_TX);
     cf pre[8];
     if (PREFETCH) fetch((long long)blockIdx.x * G + slot, pre);
+
+    // TX: a symbol's slice of the byte stream is at most N bytes = 2 dwords per thread; they are fetched one symbol
+    // ahead (the stream = [16-byte little-endian length | payload | zeros], or the plain bytes in continuous mode)
+    const int tx_nd = (MODE == M_TX) ? (p.guard ? 48 * K : N) : 0;
+    const int tx_sym_bytes = tx_nd * p.bps / 8;
+    const bool tx_raw = p.tx_raw_total >= 0;
+    const bool tx_aligned = (MODE == M_TX) && ((reinterpret_cast<uintptr_t>(p.payload) | (uintptr_t)p.payload_stride) & 3) == 0;
+    auto tx_dword = [&](const uint8_t *pay, long long len, long long by) -> unsigned { // stream bytes by .. by+3
+        if (!tx_raw && by < 16) return by < 8 ? (unsigned)((unsigned long long)len >> (8 * by)) : 0u;
+        const long long off = tx_raw ? by : by - 16;
+        if (tx_aligned && (off & 3) == 0 && off + 4 <= len) return *reinterpret_cast<const unsigned *>(pay + off);
+        unsigned v = 0;
+        for (int j = 0; j < 4; ++j) if (off + j < len) v |= (unsigned)pay[off + j] << (8 * j);
+        return v;
+    };
+    auto tx_fetch = [&](long long sg, unsigned &d0, unsigned &d1) {
+        d0 = d1 = 0u;
+        if (sg >= total) return;
+        long long f; int k;
+        split(sg, f, k);
+        long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+        if (tx_raw) { const long long left = p.tx_raw_total - f * p.payload_stride; len = left < 0 ? 0 : (left < len ? left : len); }
+        const uint8_t *pay = p.payload + f * p.payload_stride;
+        const long long sb0 = (long long)k * tx_sym_bytes;
+        if (4 * t < tx_sym_bytes + 4) d0 = tx_dword(pay, len, sb0 + 4 * t);
+        if (4 * (t + T) < tx_sym_bytes + 4) d1 = tx_dword(pay, len, sb0 + 4 * (t + T));
+    };
+    unsigned txd0 = 0, txd1 = 0;
+    if (MODE == M_TX) tx_fetch((long long)blockIdx.x * G + slot, txd0, txd1);
 
     for (long long base = (long long)blockIdx.x * G; base < total; base += (long long)gridDim.x * G) {
         const long long sigma = base + slot;
@@ -141,10 +171,26 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
         if (MODE == M_TX) {
             // modulate + encode_block (src/transmitter.rs:108-165): bin -> null / pilot / next data point
             const int nd = p.guard ? 48 * K : N;
+            const int sym_bytes = nd * p.bps / 8;           // nd is a multiple of 8
+            unsigned char *sbuf = txb + slot * (N + 8);
+            const bool raw = p.tx_raw_total >= 0;
+            long long len = 0, nsym = 0;
             if (valid) {
-                const long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
-                const uint8_t *pay = p.payload + f * p.payload_stride;
-                const long long nsym = ((16 + len) * 8 + p.bps - 1) / p.bps;
+                len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+                if (raw) { // this symbol's share of the continuous byte stream (zeros once it runs dry, transmitter.rs:158-160)
+                    const long long left = p.tx_raw_total - f * p.payload_stride;
+                    len = left < 0 ? 0 : (left < len ? left : len);
+                }
+                nsym = ((raw ? len : 16 + len) * 8 + p.bps - 1) / p.bps;
+            }
+            {   // this symbol's dwords were fetched during the previous symbol; fetch the next one's now
+                unsigned *sw = reinterpret_cast<unsigned *>(sbuf);
+                if (4 * t < sym_bytes + 4) sw[t] = txd0;
+                if (4 * (t + T) < sym_bytes + 4) sw[t + T] = txd1;
+                tx_fetch(base + (long long)gridDim.x * G + slot, txd0, txd1);
+            }
+            group_sync<T>();
+            if (valid) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     int c = c0 + 8 * m, cls = carrier_class64(c, p.guard);
@@ -154,8 +200,8 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
                         int q = p.guard ? data_classes_below64(c) * K + (t % K) : (t + m * T);
                         long long g = (long long)k * nd + q;
                         if (g < nsym) {
-                            long long bit = g * p.bps, by = bit >> 3;
-                            unsigned two = stream_byte(pay, len, by) | (stream_byte(pay, len, by + 1) << 8);
+                            const int bit = q * p.bps; // inside this symbol's slice
+                            const unsigned two = (unsigned)sbuf[bit >> 3] | ((unsigned)sbuf[(bit >> 3) + 1] << 8);
                             z = map_point((two >> (bit & 7)) & ((1u << p.bps) - 1u), p.bps);
                         }
                     }
@@ -195,7 +241,7 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
         } else if (MODE == M_IFFT_CP || MODE == M_TX) {
             // prefix_block (src/transmitter.rs:168-181): out = [x[N-CP..N), x[0..N)]
             if (valid) {
-                cf *dst = (MODE == M_TX) ? p.out + f * p.out_stride_s + (long long)(10 + k) * S : p.out + sigma * S;
+                cf *dst = (MODE == M_TX) ? p.out + f * p.out_stride_s + (long long)((p.tx_raw_total >= 0 ? 0 : 10) + k) * S : p.out + sigma * S;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     int n = t + m * T;
@@ -208,7 +254,7 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
                 // normalize, pass 1 (src/transmitter.rs:184-188): signed max over re and im, floor 0.
                 // One atomic per symbol (per wave for T > 64): symbols of one wave may belong to different frames.
                 float mine = 0.f;
-                if (valid) {
+                if (valid && p.frame_max) {
 #pragma unroll
                     for (int m = 0; m < 8; ++m) mine = fmaxf(mine, fmaxf(v[m].x, v[m].y) * (1.0f / N));
                     constexpr int W = T < 64 ? T : 64;

@@ -430,6 +430,19 @@ int ofdm_ifft_cp_batch(ofdm_ctx *c, const ofdm_fc32 *freq, ofdm_fc32 *out, int64
     HIP_TRY(c, run_ifft_cp(N, p, c->stream, c->num_cu));
     return OFDM_OK;
 }
+int ofdm_tx_symbols_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, ofdm_fc32 *out, int64_t n_sym) {
+    if (!c || n_bytes < 0 || n_sym < 0 || (n_sym && !out) || (n_bytes && !bytes)) return OFDM_ERR_INVALID;
+    const int bps_bytes = c->bytes_per_symbol();
+    if (n_sym * (int64_t)bps_bytes < n_bytes) return OFDM_ERR_INVALID; // every byte must land in a symbol
+    if (!n_sym) return OFDM_OK;
+    SymParams p = base_params(c);
+    p.n_frames = n_sym; p.syms_per_frame = 1;
+    p.payload = bytes; p.payload_stride = bps_bytes; p.payload_len = nullptr; p.payload_bytes = bps_bytes;
+    p.tx_raw_total = n_bytes;
+    p.out = reinterpret_cast<float2 *>(out); p.out_stride_s = c->S(); p.frame_max = nullptr;
+    HIP_TRY(c, run_tx_symbols(c->prm.n_fft, p, c->stream, c->num_cu));
+    return OFDM_OK;
+}
 int ofdm_unprefix_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_t n_sym) {
     if (!c || n_sym < 0 || (n_sym && (!in || !out))) return OFDM_ERR_INVALID;
     SymParams p = base_params(c);

@@ -496,6 +496,32 @@ def test_outer_rs_over_the_link(api, orc):
     assert api.decipher_transmission_bytes(api.decode(cap, True, api.BPSK)) is None
 
 
+@pytest.mark.parametrize("n,mod,guard", [(64, 6, True), (64, 1, False), (256, 4, True), (1024, 6, True), (4096, 8, True)])
+def test_tx_symbols_fused_equals_staged(api, orc, n, mod, guard):
+    """ofdm_tx_symbols_batch = modulate + encode_block + prefix_block (transmitter.rs:40-53) in one pass: same samples as
+    the three staged calls (bit for bit: same mapping and the same FFT code), and the oracle's within 1e-5."""
+    import torch
+    rng = np.random.default_rng(n + mod)
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    bps = ctx.bytes_per_symbol
+    nb = 5 * bps + bps // 3 + 1                      # the last symbol is only partly filled
+    data = rng.integers(0, 256, nb, dtype=np.uint8)
+    d = torch.from_numpy(data.copy()).to(ctx.device)
+    fused = ctx.tx_symbols(d, n_sym=7)               # 6 symbols carry bytes, the 7th only pilots
+    pts = ctx.modulate(d)
+    nd = ctx.data_carriers
+    padded = torch.zeros(7 * nd, dtype=torch.complex64, device=ctx.device)
+    padded[: pts.numel()] = pts
+    staged = ctx.prefix_block(ctx.encode_block(padded.view(7, nd)))
+    assert torch.equal(fused, staged)
+    want = []
+    opts = orc.modulate(bytes(data), mod)
+    for sidx in range(7):
+        blk, _ = orc.encode_block(opts[sidx * nd:(sidx + 1) * nd], n, guard)
+        want.append(orc.prefix_block(blk))
+    assert rel_err(host(fused), np.stack(want)) < TOL
+
+
 def test_large_batch_properties(api, orc):
     """Properties that need no oracle run, at sizes far beyond what the oracle finishes in seconds:
     TX -> RX round trip is the identity on bytes, two independent kernels (wave-centric fast path and the generic
