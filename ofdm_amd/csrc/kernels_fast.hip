@@ -236,14 +236,26 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             bfly8<false>(v);
             if (chest) { // estimate_channel: H = mean_b FFT(block_b) / training  (receiver.rs:212-229)
+                // The five spectra meet in the wave's LDS slab; lane (s, t) then owns ONE bin, t + 8 s: it adds the five
+                // values, forms H and 1/H once (not once per symbol slot), and hands 1/H back through the slab.
+                cf *slab = slab_all + wave * SLAB;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    cf h = lane_xor_sum(cmul(v[m], p.inv_training[t + 8 * m])); // 64-entry table, L2/L1 resident
-                    h = make_float2(h.x * 0.2f, h.y * 0.2f);
-                    if (p.hk && s == 0) p.hk[f * 64 + t + 8 * m] = h;
-                    const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
-                    g[m] = make_float2(h.x * rn, -h.y * rn); // 1 / H
-                }
+                for (int m = 0; m < 8; ++m) buf[t + 8 * m] = v[m];      // row s (rows 5..7 carry zeros)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int bin = t + 8 * s;
+                cf acc = slab[bin];
+#pragma unroll
+                for (int r = 1; r < 5; ++r) acc = cadd(acc, slab[r * 72 + bin]);
+                cf h = cmul(acc, p.inv_training[bin]);                   // 64-entry table, L2/L1 resident
+                h = make_float2(h.x * 0.2f, h.y * 0.2f);
+                if (p.hk) p.hk[f * 64 + bin] = h;
+                const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
+                slab[6 * 72 + bin] = make_float2(h.x * rn, -h.y * rn);   // 1 / H; row 6 is nobody's input
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int m = 0; m < 8; ++m) g[m] = slab[6 * 72 + t + 8 * m];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 continue;
             }
 #pragma unroll
