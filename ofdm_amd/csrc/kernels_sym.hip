@@ -12,6 +12,8 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+extern "C" __device__ float __ocml_atan2pi_f32(float, float); // atan2(y, x) / pi (ROCm device library)
+
 namespace ofdm {
 
 enum { M_FFT = 0, M_IFFT = 1, M_IFFT_CP = 2, M_DEMOD = 3, M_CHEST = 4, M_TX = 5 };
@@ -272,20 +274,20 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     cf hh = h[t + m * T];
-                    float ns = hh.x * hh.x + hh.y * hh.y;
+                    const float rn = __builtin_amdgcn_rcpf(hh.x * hh.x + hh.y * hh.y); // as k_rxframe64 (1 ulp)
                     cf q = cmulc(v[m], hh);
-                    v[m] = make_float2(q.x / ns, q.y / ns);
+                    v[m] = make_float2(q.x * rn, q.y * rn);
                 }
             }
             // decode_block (src/receiver.rs:106-145): mean pilot angle, rotate the data points by -phase
             if (p.guard) {
-                float ang = 0.f;
+                float ang = 0.f; // in units of pi: atan2pi / sincospi need no large-argument reduction
 #pragma unroll
                 for (int m = 0; m < 8; ++m)
-                    if (carrier_class64(c0 + 8 * m, 1) == 2) ang += atan2f(v[m].y, v[m].x);
+                    if (carrier_class64(c0 + 8 * m, 1) == 2) ang += __ocml_atan2pi_f32(v[m].y, v[m].x);
                 ang = symbol_sum<T>(ang, red, slot, t) / (4.0f * K);
                 float s, c;
-                sincosf(ang, &s, &c);
+                sincospif(ang, &s, &c);
                 const cf rot = make_float2(c, -s);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
