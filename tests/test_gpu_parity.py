@@ -293,6 +293,18 @@ def test_sc_correlate_coarse_fine_corner_cases(api, orc):
         assert found >= 60 and ties <= 24
 
 
+def test_sc_correlate_randomised_stress(ofdm):
+    """tools/sc_stress.py: 600 random captures (SNR -3..40 dB, any delay, CFO up to +-pi/80, truncated frames, second
+    packets, interferers) x 4 search configurations, every timing index / CFO / metric against the f64 oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sc_stress.py"), "600", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count(" 0 mismatches") == 4, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_sc_correlate_long_capture_multi_tile(api, orc):
     # one long capture (jetson_rx style): the frame sits past several 2560-lag tiles, odd start
     rng = np.random.default_rng(6)
