@@ -520,6 +520,192 @@ hipError_t run_txframe64(const SymParams &sp, const float2 *header, float header
     return hipErrorNotSupported;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_demod4096: RX demod of N = 4096 symbols (BASELINE config 5) as 64 x 64: one 512-thread workgroup per symbol.
+//     X[c + 64 d] = sum_b W64^(b d) * [ W4096^(b c) * sum_a x[64 a + b] W64^(a c) ]
+//   stage A  wavefront w, 8-lane group s: the FFT64 over a for column b = 8 w + s, straight from HBM in the Stockham
+//            pattern (the next symbol's loads are already in flight), in the k_demod64 layout: wave-local, no barrier;
+//   twiddle  W4096^(b c): eight loop-invariant registers per lane;
+//   transpose through LDS ([c][b], one barrier);
+//   stage B  the FFT64 over b for row c = 8 w + s, again wave-local;
+//   epilogue equalise, mean pilot angle over the 256 pilots (wave sums + one LDS step), hard decisions, LSB-first packing
+//            through LDS, dword stores -- the same arithmetic as k_sym<4096, M_DEMOD>.
+// Four radix-8 butterflies per point like the generic kernel, but ONE workgroup-wide exchange instead of three, four
+// barriers per symbol instead of nine, and ~110 VGPRs (two workgroups per CU instead of one).
+struct Big4096Params {
+    const float2 *in;
+    long long frame_stride;
+    long long total;          // symbols
+    int syms_per_frame, first_symbol;
+    const float2 *tw;         // exp(-2 pi i m / 4096), m < 4096
+    const float2 *hk;         // optional channel, hk_stride = 0 (shared) or 4096 (per frame)
+    long long hk_stride;
+    unsigned char *out;
+    long long out_stride;
+    int bps, guard;
+};
+
+template <bool GUARD>
+__global__ __launch_bounds__(512) void k_demod4096(Big4096Params p) {
+    constexpr int N = 4096, S = 5120, CP = 1024, TS = 72, SLAB = 8 * 72;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf *slab_all = reinterpret_cast<cf *>(smem);                 // [8 waves][8 x 72] FFT64 transpose slabs (stages A and B)
+    cf *T = slab_all + 8 * SLAB;                                 // [64][72]  Z[c][b]
+    unsigned char *ib = reinterpret_cast<unsigned char *>(T + 64 * TS); // [4096] hard decisions in ordinal order
+    float *red = reinterpret_cast<float *>(ib + N);              // [8] wave sums of the pilot angles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane >> 3, t = lane & 7;
+    const int col = 8 * wave + s;                 // b in stage A, c in stage B
+    cf *buf = slab_all + wave * SLAB + s * 72;
+    const int wr = swz(8 * t);
+
+    cf w[7];                                      // W64^(r t)
+#pragma unroll
+    for (int r = 1; r < 8; ++r) w[r - 1] = p.tw[64 * r * t];
+    cf z[8];                                      // W4096^(b c), c = t + 8 q
+#pragma unroll
+    for (int q = 0; q < 8; ++q) z[q] = p.tw[col * (t + 8 * q)];
+    int ord[8];                                   // data ordinal of bin c + 64 d (d = t + 8 q), -1 = null, -2 = pilot
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int d = t + 8 * q, cls = carrier_class64(d, GUARD);
+        ord[q] = cls == 0 ? (GUARD ? data_classes_below64(d) : d) * 64 + col : (cls == 2 ? -2 : -1);
+    }
+    const int nd = GUARD ? 48 * 64 : N;
+    const int nbytes = nd * p.bps / 8;
+
+    auto fetch = [&](long long sg, cf *dst) {
+        if (sg < p.total) {
+            const long long f = sg / p.syms_per_frame;
+            const int k = (int)(sg - f * p.syms_per_frame);
+            const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + k) * S + CP + col;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) dst[m] = src[64 * (t + 8 * m)];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) dst[m] = make_float2(0.f, 0.f);
+        }
+    };
+    cf pre[8];
+    fetch(blockIdx.x, pre);
+
+    for (long long sg = blockIdx.x; sg < p.total; sg += gridDim.x) {
+        const long long f = sg / p.syms_per_frame;
+        const int k = (int)(sg - f * p.syms_per_frame);
+        cf v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = pre[m];
+        fetch(sg + gridDim.x, pre);
+        // ---- stage A: FFT64 over a (wave-local)
+        bfly8<false>(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+        bfly8<false>(v);
+        // v[q] = Y_b[c = t + 8 q]; twiddle and transpose
+#pragma unroll
+        for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + col] = cmul(v[q], z[q]);
+        __syncthreads();
+        // ---- stage B: FFT64 over b for row c = col
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = T[col * TS + t + 8 * m];
+        bfly8<false>(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+        bfly8<false>(v);
+        // v[q] = X[col + 64 (t + 8 q)]
+        if (p.hk) { // equalise: Y /= H (src/receiver.rs:68-70)
+            const cf *h = p.hk + f * p.hk_stride;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const cf hh = h[col + 64 * (t + 8 * q)];
+                const float rn = __builtin_amdgcn_rcpf(hh.x * hh.x + hh.y * hh.y);
+                const cf e = cmulc(v[q], hh);
+                v[q] = make_float2(e.x * rn, e.y * rn);
+            }
+        }
+        if (GUARD) { // decode_block (src/receiver.rs:106-145): mean angle of the 4 x 64 pilots, rotate by -phase
+            // pilot classes 6, 25, 39, 58 = (t, q) = (6, 0), (1, 3), (7, 4), (2, 7); other lanes feed (1, 0) -> angle 0
+            cf pv = make_float2(1.f, 0.f);
+            pv = (t == 6) ? v[0] : pv;
+            pv = (t == 1) ? v[3] : pv;
+            pv = (t == 7) ? v[4] : pv;
+            pv = (t == 2) ? v[7] : pv;
+            float a = __ocml_atan2pi_f32(pv.y, pv.x);
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) a += __shfl_xor(a, sh, 64);
+            if (lane == 0) red[wave] = a;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tot += red[i];
+            float sn, cs;
+            sincospif(tot * (1.0f / 256.0f), &sn, &cs);
+            const cf rot = make_float2(cs, -sn);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
+        }
+        // demodulate (src/receiver.rs:147-190): hard decision per data bin -> LDS in ordinal order
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (ord[q] >= 0) ib[ord[q]] = (unsigned char)demap_point(v[q], p.bps);
+        __syncthreads();
+        {   // pack bps-bit indices LSB-first into bytes (src/utils.rs:30-36), whole dwords
+            unsigned *dst = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes);
+            for (int wd = tid; wd < nbytes / 4; wd += 512) {
+                unsigned acc = 0;
+                int i = (32 * wd) / p.bps;
+                for (;; ++i) {
+                    const int sh = i * p.bps - 32 * wd;
+                    if (sh >= 32) break;
+                    const unsigned val = ib[i];
+                    acc |= sh >= 0 ? (val << sh) : (val >> (-sh));
+                }
+                dst[wd] = acc;
+            }
+        }
+        __syncthreads(); // ib / T / red are reused by the next symbol
+    }
+}
+
+// N = 4096 RX demod fast path.  hipErrorNotSupported => caller uses k_sym<4096, M_DEMOD>.
+hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
+    if (sp.offset || sp.f_delta || sp.nsym_frame || sp.soft) return hipErrorNotSupported;
+    if (sp.syms_per_frame <= 0) return hipErrorNotSupported;
+    if ((long long)(sp.first_symbol + sp.syms_per_frame) * 5120 > sp.frame_len) return hipErrorNotSupported; // no tail padding
+    const int nd = sp.guard ? 48 * 64 : 4096;
+    if ((nd * sp.bps / 8) % 4 != 0 || (reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
+    if (sp.hk && sp.hk_stride != 0 && sp.hk_stride != 4096) return hipErrorNotSupported;
+    Big4096Params p;
+    p.in = sp.in; p.frame_stride = sp.frame_stride; p.total = sp.n_frames * (long long)sp.syms_per_frame;
+    p.syms_per_frame = sp.syms_per_frame; p.first_symbol = sp.first_symbol; p.tw = sp.tw; p.hk = sp.hk; p.hk_stride = sp.hk_stride;
+    p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.bps = sp.bps; p.guard = sp.guard;
+    if (p.total <= 0) return hipSuccess;
+    const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64;
+    static bool attr_done[2] = {false, false};
+    const int gi = sp.guard ? 1 : 0;
+    if (!attr_done[gi]) {
+        hipError_t e = sp.guard ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_demod4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                : hipFuncSetAttribute(reinterpret_cast<const void *>(k_demod4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[gi] = true;
+    }
+    long long grid = (long long)num_cu * 2;
+    if (grid > p.total) grid = p.total;
+    if (sp.guard) hipLaunchKernelGGL(k_demod4096<true>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL(k_demod4096<false>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
 template <int BPS> static hipError_t launch_bps(const Fast64Params &p, bool guard, dim3 grid, hipStream_t st) {
     const bool hk = p.hk != nullptr;
     if (guard && hk) hipLaunchKernelGGL((k_demod64<BPS, true, true>), grid, dim3(256), 0, st, p);

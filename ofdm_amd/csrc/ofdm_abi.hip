@@ -581,6 +581,12 @@ static int demod_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t fr
         if (e == hipSuccess) return OFDM_OK;
         if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
+    if (c->prm.n_fft == 4096) { // 64 x 64 two-stage kernel for regular streams (kernels_fast.hip)
+        static const bool off = getenv("OFDM_NO_DEMOD4096") != nullptr; // A/B switch
+        hipError_t e = off ? hipErrorNotSupported : run_demod4096(p, c->stream, c->num_cu);
+        if (e == hipSuccess) return OFDM_OK;
+        if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
+    }
     HIP_TRY(c, run_demod(c->prm.n_fft, p, c->stream, c->num_cu));
     return OFDM_OK;
 }
