@@ -706,6 +706,147 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_tx4096: modulate + encode_block + prefix_block (src/transmitter.rs:108-181) for a continuous stream of N = 4096
+// symbols (BASELINE config 5 TX), the mirror image of k_demod4096:
+//     x[c + 64 d] = 1/N sum_b W64^(-b d) * [ W4096^(-b c) * sum_a X[64 a + b] W64^(-a c) ]
+// The symbol's bytes are staged in LDS from dwords prefetched one symbol ahead; lane (s, t) of wavefront w builds bins
+// 64 (t + 8 m) + b, b = 8 w + s (the carrier class depends on t + 8 m only), runs the inverse FFT64 over a, the twiddle,
+// the LDS transpose and the inverse FFT64 over b, and stores samples c + 64 (t + 8 q) behind the cyclic prefix.
+struct Tx4096Params {
+    const uint8_t *bytes;
+    long long n_bytes, n_sym;
+    const float2 *tw;   // exp(-2 pi i m / 4096)
+    float2 *out;        // n_sym x 5120 samples
+    int bps, guard;
+};
+
+template <bool GUARD>
+__global__ __launch_bounds__(512) void k_tx4096(Tx4096Params p) {
+    constexpr int N = 4096, S = 5120, CP = 1024, TS = 72, SLAB = 8 * 72;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf *slab_all = reinterpret_cast<cf *>(smem);
+    cf *T = slab_all + 8 * SLAB;
+    unsigned *sbw = reinterpret_cast<unsigned *>(T + 64 * TS);          // [1024 + 2] the symbol's bytes as dwords
+    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane >> 3, t = lane & 7;
+    const int col = 8 * wave + s;
+    cf *buf = slab_all + wave * SLAB + s * 72;
+    const int wr = swz(8 * t);
+    cf w[7];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { const cf x = p.tw[64 * r * t]; w[r - 1] = make_float2(x.x, -x.y); }
+    cf z[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const cf x = p.tw[col * (t + 8 * q)]; z[q] = make_float2(x.x, -x.y); }
+    int boff[8]; // bit offset of bin 64 (t + 8 m) + col inside the symbol's stream, -1 = null, -2 = pilot
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int a = t + 8 * m, cls = carrier_class64(a, GUARD);
+        boff[m] = cls == 0 ? ((GUARD ? data_classes_below64(a) : a) * 64 + col) * p.bps : (cls == 2 ? -2 : -1);
+    }
+    const int nd = GUARD ? 48 * 64 : N;
+    const int sym_bytes = nd * p.bps / 8;   // <= 4096, multiple of 4 (checked by the launcher)
+    const bool aligned = (reinterpret_cast<uintptr_t>(p.bytes) & 3) == 0;
+    auto dword = [&](long long by) -> unsigned { // stream bytes by .. by + 3, zero past the end
+        if (aligned && by + 4 <= p.n_bytes) return *reinterpret_cast<const unsigned *>(p.bytes + by);
+        unsigned v = 0;
+        for (int j = 0; j < 4; ++j) if (by + j < p.n_bytes) v |= (unsigned)p.bytes[by + j] << (8 * j);
+        return v;
+    };
+    auto fetch = [&](long long sg, unsigned &d0, unsigned &d1) {
+        d0 = d1 = 0u;
+        if (sg >= p.n_sym) return;
+        const long long base = sg * sym_bytes;
+        if (4 * tid < sym_bytes) d0 = dword(base + 4 * tid);
+        if (4 * (tid + 512) < sym_bytes) d1 = dword(base + 4 * (tid + 512));
+    };
+    unsigned d0, d1;
+    fetch(blockIdx.x, d0, d1);
+
+    for (long long sg = blockIdx.x; sg < p.n_sym; sg += gridDim.x) {
+        sbw[tid] = d0;
+        sbw[tid + 512] = d1;
+        if (tid < 2) sbw[1024 + tid] = 0u; // slack for the two-byte window
+        fetch(sg + gridDim.x, d0, d1);
+        __syncthreads();
+        long long left = p.n_bytes - sg * sym_bytes;             // stream bytes that belong to this symbol
+        left = left < 0 ? 0 : (left < sym_bytes ? left : sym_bytes);
+        const int live_bits = (int)(((left * 8 + p.bps - 1) / p.bps) * p.bps); // fields that carry stream bits; the rest are 0
+        cf v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            cf pt = make_float2(0.f, 0.f);
+            if (boff[m] == -2) pt = make_float2(1.f, 0.f);
+            else if (boff[m] >= 0 && boff[m] < live_bits) {
+                const int bit = boff[m];
+                const unsigned two = (unsigned)sb[bit >> 3] | ((unsigned)sb[(bit >> 3) + 1] << 8);
+                pt = map_point((two >> (bit & 7)) & ((1u << p.bps) - 1u), p.bps);
+            }
+            v[m] = pt;
+        }
+        bfly8<true>(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+        bfly8<true>(v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + col] = cmul(v[q], z[q]);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = T[col * TS + t + 8 * m];
+        bfly8<true>(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+        bfly8<true>(v);
+        // v[q] = N x[col + 64 (t + 8 q)]; prefix_block: out = [x[N - CP .. N), x[0 .. N)]
+        cf *dst = p.out + sg * S;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = col + 64 * (t + 8 * q);
+            const cf y = make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N));
+            dst[CP + n] = y;
+            if (n >= N - CP) dst[n - (N - CP)] = y;
+        }
+        __syncthreads(); // sbw / T are reused by the next symbol
+    }
+}
+
+// Continuous-stream TX for N = 4096.  hipErrorNotSupported => caller uses k_sym<4096, M_TX>.
+hipError_t run_tx4096(const SymParams &sp, hipStream_t st, int num_cu) {
+    if (sp.tx_raw_total < 0 || sp.syms_per_frame != 1 || sp.payload_len) return hipErrorNotSupported;
+    const int nd = sp.guard ? 48 * 64 : 4096;
+    const int sym_bytes = nd * sp.bps / 8;
+    if ((sym_bytes & 3) || sp.payload_stride != sym_bytes || sp.out_stride_s != 5120) return hipErrorNotSupported;
+    if (sp.n_frames <= 0) return hipSuccess;
+    Tx4096Params p;
+    p.bytes = sp.payload; p.n_bytes = sp.tx_raw_total; p.n_sym = sp.n_frames; p.tw = sp.tw; p.out = sp.out; p.bps = sp.bps; p.guard = sp.guard;
+    const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64;
+    static bool attr_done[2] = {false, false};
+    const int gi = sp.guard ? 1 : 0;
+    if (!attr_done[gi]) {
+        hipError_t e = sp.guard ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_tx4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                : hipFuncSetAttribute(reinterpret_cast<const void *>(k_tx4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[gi] = true;
+    }
+    long long grid = (long long)num_cu * 2;
+    if (grid > p.n_sym) grid = p.n_sym;
+    if (sp.guard) hipLaunchKernelGGL(k_tx4096<true>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL(k_tx4096<false>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
 template <int BPS> static hipError_t launch_bps(const Fast64Params &p, bool guard, dim3 grid, hipStream_t st) {
     const bool hk = p.hk != nullptr;
     if (guard && hk) hipLaunchKernelGGL((k_demod64<BPS, true, true>), grid, dim3(256), 0, st, p);

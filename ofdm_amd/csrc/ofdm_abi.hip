@@ -440,6 +440,12 @@ int ofdm_tx_symbols_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, of
     p.payload = bytes; p.payload_stride = bps_bytes; p.payload_len = nullptr; p.payload_bytes = bps_bytes;
     p.tx_raw_total = n_bytes;
     p.out = reinterpret_cast<float2 *>(out); p.out_stride_s = c->S(); p.frame_max = nullptr;
+    if (c->prm.n_fft == 4096) { // 64 x 64 two-stage kernel (kernels_fast.hip)
+        static const bool off = getenv("OFDM_NO_DEMOD4096") != nullptr; // A/B switch shared with the RX side
+        hipError_t e = off ? hipErrorNotSupported : run_tx4096(p, c->stream, c->num_cu);
+        if (e == hipSuccess) return OFDM_OK;
+        if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
+    }
     HIP_TRY(c, run_tx_symbols(c->prm.n_fft, p, c->stream, c->num_cu));
     return OFDM_OK;
 }

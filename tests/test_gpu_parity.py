@@ -514,8 +514,9 @@ def test_outer_rs_over_the_link(api, orc):
 
 @pytest.mark.parametrize("n,mod,guard", [(64, 6, True), (64, 1, False), (256, 4, True), (1024, 6, True), (4096, 8, True)])
 def test_tx_symbols_fused_equals_staged(api, orc, n, mod, guard):
-    """ofdm_tx_symbols_batch = modulate + encode_block + prefix_block (transmitter.rs:40-53) in one pass: same samples as
-    the three staged calls (bit for bit: same mapping and the same FFT code), and the oracle's within 1e-5."""
+    """ofdm_tx_symbols_batch = modulate + encode_block + prefix_block (transmitter.rs:40-53) in one pass: the samples of the
+    three staged calls -- bit for bit where the same FFT code runs, within 1e-5 for N = 4096 (64 x 64 two-stage kernel) --
+    and the oracle's within 1e-5."""
     import torch
     rng = np.random.default_rng(n + mod)
     ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
@@ -529,7 +530,10 @@ def test_tx_symbols_fused_equals_staged(api, orc, n, mod, guard):
     padded = torch.zeros(7 * nd, dtype=torch.complex64, device=ctx.device)
     padded[: pts.numel()] = pts
     staged = ctx.prefix_block(ctx.encode_block(padded.view(7, nd)))
-    assert torch.equal(fused, staged)
+    if n == 4096:
+        assert rel_err(host(fused), host(staged)) < TOL
+    else:
+        assert torch.equal(fused, staged)
     want = []
     opts = orc.modulate(bytes(data), mod)
     for sidx in range(7):

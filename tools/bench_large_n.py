@@ -21,7 +21,7 @@ def cfg5(n_sym=65536, steps=5):
     for _ in range(steps): x = tx()
     tx_staged_ms = ctx.timer_stop_ms() / steps
     xf = ctx.tx_symbols(pay); torch.cuda.synchronize()          # the same three stages in one pass
-    same = bool(torch.equal(xf.view(-1), x.view(-1)))
+    same = float((xf.view(-1) - x.view(-1)).abs().max() / x.view(-1).abs().max())  # 64 x 64 kernel vs staged radix-8 passes
     ctx.timer_start()
     for _ in range(steps): xf = ctx.tx_symbols(pay)
     tx_ms = ctx.timer_stop_ms() / steps
@@ -34,7 +34,7 @@ def cfg5(n_sym=65536, steps=5):
     ok = bool((out.view(-1) == pay).all())
     ns = n_sym * ctx.S
     return {"workload": "cfg5: N=4096 256QAM guard, continuous symbols", "symbols": n_sym, "tx_ms": tx_ms, "rx_ms": rx_ms,
-            "tx_msamples_per_s": ns / tx_ms / 1e3, "tx_staged_ms": tx_staged_ms, "tx_fused_equals_staged": same,
+            "tx_msamples_per_s": ns / tx_ms / 1e3, "tx_staged_ms": tx_staged_ms, "tx_fused_vs_staged_max_rel_err": same,
             "rx_msamples_per_s": ns / rx_ms / 1e3,
             "rx_hbm_frac": (ns * 8 + nb) / (rx_ms / 1e3) / 8e12, "rx_bytes_equal_tx_payload": ok}
 
