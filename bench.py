@@ -186,6 +186,16 @@ def main():
         except Exception as e:  # the headline number must not be lost to the secondary report
             res["cfg3"] = {"error": repr(e)}
 
+    if rank == 0 and n_gpus == 1 and not a.no_cfg3:
+        try:  # configs 4 and 5 on this GPU (N = 1024 chain, N = 4096 TX + RX): a few seconds, informational
+            from tools import bench_large_n
+
+            torch.cuda.empty_cache()
+            res["cfg5"] = bench_large_n.cfg5(steps=3)
+            res["cfg4"] = bench_large_n.cfg4(steps=3)
+        except Exception as e:
+            res["cfg45_error"] = repr(e)
+
     if rank == 0:
         print(json.dumps(res))
     grp.close()
