@@ -339,13 +339,19 @@ class Context:
         return (out, soft) if want_soft else out
 
     # ---------------------------------------------------------------- pipelines
-    def encode_batch(self, payload: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """encode (src/transmitter.rs:11-58) for every row of payload [n_frames, payload_bytes] (uint8)."""
+    def encode_batch(self, payload: torch.Tensor, out: Optional[torch.Tensor] = None,
+                     lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """encode (src/transmitter.rs:11-58) for every row of payload [n_frames, payload_bytes] (uint8).
+        lens (int32 [n_frames], optional): true payload length of every row (<= payload_bytes); every frame still has
+        the slot size of payload_bytes, its unused tail symbols carry pilots only."""
         payload = self._u8(payload)
         n, nbytes = payload.shape
         frame = self.frame_samples(nbytes)
         out = self.empty((n, frame), torch.complex64) if out is None else self._cx(out)
-        self._ck(self.lib.ofdm_tx_encode_batch(self.h, _dev(payload), n, nbytes, None, nbytes, _dev(out), out.shape[-1]),
+        if lens is not None:
+            lens = lens.to(device=self.device, dtype=torch.int32).contiguous()
+            assert lens.numel() == n
+        self._ck(self.lib.ofdm_tx_encode_batch(self.h, _dev(payload), n, nbytes, _dev(lens), nbytes, _dev(out), out.shape[-1]),
                  "tx_encode")
         return out
 

@@ -542,6 +542,28 @@ def test_tx_symbols_fused_equals_staged(api, orc, n, mod, guard):
     assert rel_err(host(fused), np.stack(want)) < TOL
 
 
+@pytest.mark.parametrize("n,mod,guard", [(64, 6, True), (64, 2, False), (256, 4, True)])
+def test_tx_encode_ragged_lengths(api, orc, n, mod, guard):
+    """ofdm_tx_encode_batch with per-frame payload lengths (payload_len_dev): every frame occupies the slot of the longest
+    payload; up to its own last data symbol it equals the oracle's frame for that payload (the pilot-only tail symbols
+    are far below the frame maximum, so the normalisation is the same), and it decodes to its own length."""
+    import torch
+    rng = np.random.default_rng(n + mod)
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    maxb = 300
+    lens = [300, 0, 1, 137, 299, 300]
+    pay = rng.integers(0, 256, (len(lens), maxb), dtype=np.uint8)
+    frames = host(ctx.encode_batch(torch.from_numpy(pay).to(ctx.device), lens=torch.tensor(lens, dtype=torch.int32)))
+    S = ctx.S
+    for f, ln in enumerate(lens):
+        want = orc.encode(bytes(pay[f, :ln]), guard, mod, n)
+        assert rel_err(frames[f][: want.size], want) < TOL, f"frame {f} (len {ln})"
+        tail = frames[f][want.size:]
+        assert tail.size % S == 0 and (tail.size == 0 or np.abs(tail).max() <= np.abs(frames[f][: want.size]).max())
+        cap = through_channel(orc, rng, wide(frames[f]), frames[f].size + 120, 33, 0.003, snr_db=40.0, data_start=10 * S)
+        assert api.decode(wide(cap), guard, mod, n_fft=n) == bytes(pay[f, :ln])
+
+
 def test_large_batch_properties(api, orc):
     """Properties that need no oracle run, at sizes far beyond what the oracle finishes in seconds:
     TX -> RX round trip is the identity on bytes, two independent kernels (wave-centric fast path and the generic
