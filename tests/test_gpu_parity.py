@@ -564,6 +564,30 @@ def test_tx_encode_ragged_lengths(api, orc, n, mod, guard):
         assert api.decode(wide(cap), guard, mod, n_fft=n) == bytes(pay[f, :ln])
 
 
+def test_set_stream_and_memset(api, orc):
+    """ofdm_set_stream: the context enqueues on whatever HIP stream the host hands it (here a torch side stream);
+    ofdm_memset: device fill on that stream."""
+    import ctypes as C
+    import torch
+    ctx = api.Context(modulation=api.QAM64, guard_bands=True)
+    side = torch.cuda.Stream(device=ctx.device)
+    rng = np.random.default_rng(3)
+    x, data = make_symbols(orc, rng, 16, 64, True, 6)
+    with torch.cuda.stream(side):
+        xd = ctx.to_device(x).view(1, -1)
+        out = torch.empty((1, 16 * ctx.bytes_per_symbol), dtype=torch.uint8, device=ctx.device)
+        ctx._ck(ctx.lib.ofdm_set_stream(ctx.h, C.c_void_p(side.cuda_stream)), "set_stream")
+        ctx._ck(ctx.lib.ofdm_memset(ctx.h, C.c_void_p(out.data_ptr()), 0xA5, out.numel()), "memset")
+        side.synchronize()
+        assert bool((out == 0xA5).all())
+        ctx.rx_demod(xd, syms_per_frame=16, out=out)
+        ctx.synchronize()                       # ofdm_synchronize waits on the context's (= side) stream
+    assert bytes(out.cpu().numpy()[0]) == orc.rx_demod(wide(x), 64, True, orc.QAM64) == data
+    ctx._ck(ctx.lib.ofdm_set_stream(ctx.h, None), "set_stream")   # back to the device's default stream
+    assert bytes(ctx.rx_demod(xd, syms_per_frame=16).cpu().numpy()[0]) == data
+    assert ctx.lib.ofdm_set_stream(None, None) == -1 and ctx.lib.ofdm_memset(ctx.h, None, 0, 8) == -1
+
+
 def test_large_batch_properties(api, orc):
     """Properties that need no oracle run, at sizes far beyond what the oracle finishes in seconds:
     TX -> RX round trip is the identity on bytes, two independent kernels (wave-centric fast path and the generic
