@@ -691,13 +691,10 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.bps = sp.bps; p.guard = sp.guard;
     if (p.total <= 0) return hipSuccess;
     const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64;
-    static bool attr_done[2] = {false, false};
-    const int gi = sp.guard ? 1 : 0;
-    if (!attr_done[gi]) {
+    {   // > 64 KB of dynamic LDS: per device, so set on every call (one process may drive several GPUs); once per batch
         hipError_t e = sp.guard ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_demod4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                                 : hipFuncSetAttribute(reinterpret_cast<const void *>(k_demod4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done[gi] = true;
     }
     long long grid = (long long)num_cu * 2;
     if (grid > p.total) grid = p.total;
@@ -832,13 +829,10 @@ hipError_t run_tx4096(const SymParams &sp, hipStream_t st, int num_cu) {
     Tx4096Params p;
     p.bytes = sp.payload; p.n_bytes = sp.tx_raw_total; p.n_sym = sp.n_frames; p.tw = sp.tw; p.out = sp.out; p.bps = sp.bps; p.guard = sp.guard;
     const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64;
-    static bool attr_done[2] = {false, false};
-    const int gi = sp.guard ? 1 : 0;
-    if (!attr_done[gi]) {
+    {   // > 64 KB of dynamic LDS: per device, so set on every call (one process may drive several GPUs); once per batch
         hipError_t e = sp.guard ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_tx4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                                 : hipFuncSetAttribute(reinterpret_cast<const void *>(k_tx4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done[gi] = true;
     }
     long long grid = (long long)num_cu * 2;
     if (grid > p.n_sym) grid = p.n_sym;
