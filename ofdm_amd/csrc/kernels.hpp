@@ -60,6 +60,8 @@ struct Fast64Params {
 hipError_t run_demod64_fast(const SymParams &p, hipStream_t st, int num_cu);
 // N = 4096 RX demod as 64 x 64 (regular streams: no offset / CFO / per-frame symbol counts / soft output)
 hipError_t run_demod4096(const SymParams &p, hipStream_t st, int num_cu);
+// fused estimate_channel + per-symbol demod for N = 1024 frames (16 x 64 FFT), the N = 1024 analogue of run_rxframe64
+hipError_t run_rxframe1024(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu);
 // N = 4096 continuous-stream TX (map + IFFT + CP) as 64 x 64; needs tx_raw_total >= 0
 hipError_t run_tx4096(const SymParams &p, hipStream_t st, int num_cu);
 // fused estimate_channel + per-symbol demod for N = 64 frames with per-frame offset / CFO / live-symbol count

@@ -684,6 +684,16 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     // 3+4. channel estimate from the 5 training blocks and per data symbol CP strip + FFT + equalise + pilot phase +
     //      demap (receiver.rs:44-83).  N = 64: one fused wave-centric kernel; otherwise the generic pair.
     bool fused = false;
+    if (N == 1024) { // one workgroup per frame: channel estimate kept in registers, 16 x 64 FFT (kernels_fast.hip)
+        static const bool off = getenv("OFDM_NO_RXFRAME1024") != nullptr; // A/B switch
+        SymParams p = base_params(c);
+        p.in = x; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
+        p.offset = offs; p.f_delta = fd; p.nsym_frame = (const int32_t *)w_nsym;
+        p.out_bytes = (uint8_t *)w_raw; p.out_stride = raw_stride;
+        hipError_t e = off ? hipErrorNotSupported : run_rxframe1024(p, nullptr, c->stream, c->num_cu);
+        if (e == hipSuccess) fused = true;
+        else if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
+    }
     if (N == 64) {
         SymParams p = base_params(c);
         p.in = x; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
