@@ -9,12 +9,14 @@ from util import decision_margin, through_channel, wide
 from ofdm_amd import api
 from oracle import oracle as orc
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+n_all = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 TOL = 1e-5
 bad = tot_exc = 0
 for (nf, mod, guard, ecc, nbytes, snr) in ((64, 6, True, 0, 560, 30.0), (64, 6, True, 0, 560, 22.0), (64, 2, False, 0, 400, 15.0),
-                                            (64, 4, True, 1, 300, 25.0), (64, 8, True, 0, 500, 35.0), (64, 1, True, 0, 90, 8.0)):
+                                            (64, 4, True, 1, 300, 25.0), (64, 8, True, 0, 500, 35.0), (64, 1, True, 0, 90, 8.0),
+                                            (1024, 6, True, 1, 1536, 28.0), (1024, 4, False, 0, 2000, 20.0), (256, 6, True, 0, 700, 26.0)):
+    n = n_all if nf == 64 else max(8, n_all // (nf // 32))   # the oracle's full-lag search is O(N^2) per frame
     rng = np.random.default_rng(seed)
     S = nf + nf // 4
     ctx = api.Context(n_fft=nf, modulation=mod, guard_bands=guard, ecc=ecc)
