@@ -451,6 +451,35 @@ def test_rx_decode_batch_variants(api, orc, n, mod, guard, ecc, nbytes, cfo_abs)
     assert errs / (6 * nbytes * 8) < 5e-3
 
 
+@pytest.mark.parametrize("n,mod,guard", [(1024, 4, True), (1024, 6, False), (64, 6, True)])
+def test_rx_decode_truncated_and_limited(api, orc, n, mod, guard):
+    """The fused per-frame kernels (k_rxframe64 / k_rxframe1024) on captures that END inside a data symbol (pad_chunk,
+    receiver.rs:203-210: the tail is zero-filled and demodulated as garbage, then cut by the length header) and with
+    max_symbols smaller than the frame (fewer live symbols): status, offset and bytes equal the oracle's."""
+    rng = np.random.default_rng(n + mod)
+    S = n + n // 4
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    nbytes = 900 if n == 1024 else 300
+    D = ctx.data_symbols(nbytes)
+    caps, cuts = [], []
+    for f in range(6):
+        pay = bytes(rng.integers(0, 256, nbytes, dtype=np.uint8))
+        tx = orc.encode(pay, guard, mod, n)
+        full = through_channel(orc, rng, tx, tx.size + 200, 20 + 7 * f, 0.002 * (f - 2) / (n / 64), 32.0, data_start=10 * S)
+        cut = full.size if f == 0 else full.size - 200 - int(rng.integers(1, 2 * S))   # frames 1..5 lose part of their tail
+        c = full.copy(); c[cut:] = 0
+        caps.append(c); cuts.append(cut)
+    caps = np.stack(caps)
+    for max_sym in (D, max(1, D - 2)):
+        res = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=max_sym).items()}
+        for f in range(6):
+            w = orc.decode_sc(wide(caps[f]), guard, mod, n, max_symbols=max_sym)
+            assert res["status"][f] == w["status"], (f, max_sym)
+            if w["status"] == 0:
+                assert res["offset"][f] == w["offset"] and abs(res["f_delta"][f] - w["f_delta"]) <= 1e-9
+                assert bytes(res["bytes"][f][: res["len"][f]]) == w["bytes"], (f, max_sym)
+
+
 def test_decode_errors(api, orc):
     # "Input not long enough, bailing early" (receiver.rs:27-29) and no-sync
     rng = np.random.default_rng(4)
