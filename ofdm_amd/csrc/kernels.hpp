@@ -65,7 +65,10 @@ hipError_t run_rxframe1024(const SymParams &p, float2 *hk_out, hipStream_t st, i
 // N = 4096 continuous-stream TX (map + IFFT + CP) as 64 x 64; needs tx_raw_total >= 0
 hipError_t run_tx4096(const SymParams &p, hipStream_t st, int num_cu);
 // fused estimate_channel + per-symbol demod for N = 64 frames with per-frame offset / CFO / live-symbol count
-hipError_t run_rxframe64(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu);
+// final_out / final_stride / final_len (optional, 4-byte aligned): also do the length-header parse + truncate and write the
+// payload bytes to their final place (no outer code), so that no separate finish kernel is needed
+hipError_t run_rxframe64(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu, unsigned char *final_out = nullptr,
+                         long long final_stride = 0, int32_t *final_len = nullptr);
 // fused encode for N = 64 (map + IFFT + CP + header + normalise, one HBM pass); hipErrorNotSupported outside its envelope
 hipError_t run_txframe64(const SymParams &p, const float2 *header, float header_max, hipStream_t st, int num_cu);
 

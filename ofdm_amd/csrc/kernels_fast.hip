@@ -153,6 +153,11 @@ struct RxFrame64Params {
     unsigned char *out;        // raw decoded bytes, nsym * bytes_per_symbol per frame
     long long out_stride;
     float2 *hk;                // optional: channel estimate per frame (64 bins)
+    // optional fused "finish" (length header parse + truncate, src/receiver.rs:85-95; no outer code): when final_out is set the
+    // decoded bytes go straight to their final place (raw byte 16 + i -> final byte i, i < length) and `out` is unused
+    unsigned char *final_out;
+    long long final_stride;
+    int32_t *final_len;
 };
 
 __device__ __forceinline__ cf lane_xor_sum(cf v) { // sum over the 8 symbol slots: lanes with equal (lane & 7)
@@ -192,10 +197,11 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
 
     for (long long f = (long long)blockIdx.x * 4 + wave; f < p.n_frames; f += (long long)gridDim.x * 4) {
         const int ns = p.nsym[f];
-        if (ns <= 0) continue; // wave-uniform
+        if (ns <= 0) { if (p.final_out && lane == 0) p.final_len[f] = 0; continue; } // wave-uniform
         const long long off = p.offset ? p.offset[f] : 0;
         const double turns = p.f_delta ? p.f_delta[f] * 0.15915494309189533577 : 0.0;
         const cf st = cfo_phasor(turns, 8);
+        int keep = 0; // fused finish: bytes of this frame's output (known once the first group is demodulated)
         const cf *src = p.in + f * p.frame_stride + off;
         const long long avail = p.frame_len - off; // samples of the trimmed frame
 
@@ -285,9 +291,27 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
                     }
                 }
             }
-            unsigned *dst = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k0 * SYM_BYTES);
             const int ndw = count * (SYM_BYTES / 4);
-            for (int i = lane; i < ndw; i += 64) dst[i] = img[i];
+            if (p.final_out) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the image is complete
+                if (k0 == 0) { // bincode fixint little-endian u128 length (src/packets/mod.rs:20-32), then Vec::truncate
+                    const unsigned long long lo = (unsigned long long)img[0] | ((unsigned long long)img[1] << 32);
+                    const unsigned long long hi = (unsigned long long)img[2] | ((unsigned long long)img[3] << 32);
+                    const int body = ns * SYM_BYTES - 16;
+                    keep = (hi == 0 && lo < (unsigned long long)body) ? (int)lo : body;
+                    if (lane == 0) p.final_len[f] = keep;
+                }
+                unsigned char *fo = p.final_out + f * p.final_stride;
+                for (int i = lane; i < ndw; i += 64) {
+                    const int ob = k0 * SYM_BYTES + 4 * i - 16; // final byte index of this dword
+                    if (ob < 0 || ob >= keep) continue;
+                    if (ob + 4 <= keep) *reinterpret_cast<unsigned *>(fo + ob) = img[i];
+                    else for (int j = 0; ob + j < keep; ++j) fo[ob + j] = (unsigned char)(img[i] >> (8 * j));
+                }
+            } else {
+                unsigned *dst = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k0 * SYM_BYTES);
+                for (int i = lane; i < ndw; i += 64) dst[i] = img[i];
+            }
         }
     }
 }
@@ -299,7 +323,8 @@ template <int BPS> static hipError_t launch_rxframe(const RxFrame64Params &p, bo
 }
 
 // Fused channel estimate + demod for N = 64 frames.  hipErrorNotSupported => caller uses run_chest + run_demod.
-hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, int num_cu) {
+hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, int num_cu, unsigned char *final_out,
+                         long long final_stride, int32_t *final_len) {
     const int nd = sp.guard ? 48 : 64;
     if ((nd * sp.bps / 8) % 4 != 0 || !sp.nsym_frame || sp.soft) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
@@ -308,6 +333,10 @@ hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, in
     p.in = sp.in; p.n_frames = sp.n_frames; p.frame_stride = sp.frame_stride; p.frame_len = sp.frame_len;
     p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym = sp.nsym_frame; p.tw = sp.tw; p.inv_training = sp.inv_training;
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.hk = hk_out;
+    p.final_out = nullptr; p.final_stride = 0; p.final_len = nullptr;
+    if (final_out && final_len && (reinterpret_cast<uintptr_t>(final_out) & 3) == 0 && (final_stride & 3) == 0) {
+        p.final_out = final_out; p.final_stride = final_stride; p.final_len = final_len;
+    } else if (final_out) return hipErrorNotSupported;
     long long blocks = (sp.n_frames + 3) / 4, cap = (long long)num_cu * 8;
     const dim3 grid((unsigned)(blocks < cap ? blocks : cap));
     switch (sp.bps) {

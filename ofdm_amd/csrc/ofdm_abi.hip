@@ -683,7 +683,7 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
                               c->prm.cfo_mode, max_symbols, bps_bytes, status, offs, (int32_t *)w_nsym, c->stream));
     // 3+4. channel estimate from the 5 training blocks and per data symbol CP strip + FFT + equalise + pilot phase +
     //      demap (receiver.rs:44-83).  N = 64: one fused wave-centric kernel; otherwise the generic pair.
-    bool fused = false;
+    bool fused = false, finished = false;
     if (N == 1024) { // one workgroup per frame: channel estimate kept in registers, 16 x 64 FFT (kernels_fast.hip)
         static const bool off = getenv("OFDM_NO_RXFRAME1024") != nullptr; // A/B switch
         SymParams p = base_params(c);
@@ -699,8 +699,11 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         p.in = x; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
         p.offset = offs; p.f_delta = fd; p.nsym_frame = (const int32_t *)w_nsym;
         p.out_bytes = (uint8_t *)w_raw; p.out_stride = raw_stride;
-        hipError_t e = run_rxframe64(p, nullptr, c->stream, c->num_cu);
-        if (e == hipSuccess) fused = true;
+        // without an outer code the kernel also parses the length header and writes the payload to its final place
+        const bool fin = c->prm.ecc == OFDM_ECC_NONE && (reinterpret_cast<uintptr_t>(out) & 3) == 0 && (out_stride & 3) == 0;
+        hipError_t e = fin ? run_rxframe64(p, nullptr, c->stream, c->num_cu, out, out_stride, out_len)
+                           : run_rxframe64(p, nullptr, c->stream, c->num_cu);
+        if (e == hipSuccess) { fused = true; finished = fin; }
         else if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
     if (!fused) {
@@ -713,8 +716,9 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         if (rc) return rc;
     }
     // 5. length header, truncate [, Hamming decode] (receiver.rs:85-95)
-    HIP_TRY(c, run_rx_finish((const uint8_t *)w_raw, raw_stride, n_frames, status, (const int32_t *)w_nsym, bps_bytes,
-                             c->prm.ecc, out, out_stride, out_len, c->stream));
+    if (!finished)
+        HIP_TRY(c, run_rx_finish((const uint8_t *)w_raw, raw_stride, n_frames, status, (const int32_t *)w_nsym, bps_bytes,
+                                 c->prm.ecc, out, out_stride, out_len, c->stream));
     return OFDM_OK;
 }
 
