@@ -672,7 +672,9 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     ScFastParams q;
     q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride;
     const long long tile_n = (long long)nch * 10;
-    const long long stage = p.frame_len < tile_n ? p.frame_len : tile_n;
+    long long stage = p.frame_len < tile_n ? p.frame_len : tile_n;
+    const long long needed = (p.n_lags + p.W + p.L + 10 + 1) & ~1LL; // the last searched lag's window, plus the slide's reach
+    if (needed < stage) stage = needed;                               // bounded searches stage (and sum) only what they use
     q.n16 = (int)(stage / 2);
     q.n_lags = (int)p.n_lags; q.L = p.L; q.W = p.W;
     { const char *dbg = getenv("OFDM_SC_DEBUG"); q.debug = dbg ? atoi(dbg) : 0; }
@@ -681,7 +683,7 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     q.d_hat = p.d_hat; q.slow_list = slow_list; q.slow_count = slow_count; q.exact = exact;
     // persistent over the frames; workgroups per CU bounded by LDS (22.5 KB for a 2176-sample frame -> 7)
     static const int per_cu_cap = [] { const char *v = getenv("OFDM_SC_WG_PER_CU"); return v ? atoi(v) : 7; }(); // tuning knob
-    const size_t lds = sc_cf_lds_bytes(p.L, nch, p.frame_len);
+    const size_t lds = sc_cf_lds_bytes(p.L, nch, stage);
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
     if (per_cu > per_cu_cap) per_cu = per_cu_cap;
     if (per_cu < 1) per_cu = 1;
