@@ -1,5 +1,12 @@
-// kernels_fast.hip -- the N = 64 RX-demod fast path (BASELINE config 2): CP strip + FFT64 + [equalise] + pilot
-// phase + hard demap + LSB-first bit packing, for regularly spaced, HBM-resident symbols.
+// kernels_fast.hip -- the shape-specialised kernels of the hot path (everything else is the generic k_sym):
+//   k_demod64      N = 64 RX demod for regular streams (BASELINE config 2, the headline)      -- described below
+//   k_rxframe64    N = 64 per-frame receive body after timing (config 3): channel estimate + demod [+ finish]
+//   k_txframe64    N = 64 encode: frame built in LDS, one HBM pass
+//   k_rxframe1024  N = 1024 per-frame receive body (config 4), FFT as 16 x 64
+//   k_demod4096 / k_tx4096   N = 4096 RX demod / continuous TX (config 5), FFT as 64 x 64
+//
+// k_demod64: CP strip + FFT64 + [equalise] + pilot phase + hard demap + LSB-first bit packing, for regularly spaced,
+// HBM-resident symbols.
 //
 // Wave-centric: one 64-lane wavefront owns 8 consecutive OFDM symbols (8 lanes x 8 points each) per iteration and
 // never meets a workgroup barrier.  Per iteration and lane:
