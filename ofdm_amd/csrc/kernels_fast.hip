@@ -581,14 +581,16 @@ struct Big4096Params {
     int bps, guard;
 };
 
-template <bool GUARD>
+template <int BPS, bool GUARD>
 __global__ __launch_bounds__(512) void k_demod4096(Big4096Params p) {
     constexpr int N = 4096, S = 5120, CP = 1024, TS = 72, SLAB = 8 * 72;
+    constexpr int ND = GUARD ? 48 * 64 : N;
+    constexpr int IMG_DW = ND * BPS / 32;                        // packed bytes of one symbol, in dwords (<= 1024)
     extern __shared__ __align__(16) unsigned char smem[];
     cf *slab_all = reinterpret_cast<cf *>(smem);                 // [8 waves][8 x 72] FFT64 transpose slabs (stages A and B)
     cf *T = slab_all + 8 * SLAB;                                 // [64][72]  Z[c][b]
-    unsigned char *ib = reinterpret_cast<unsigned char *>(T + 64 * TS); // [4096] hard decisions in ordinal order
-    float *red = reinterpret_cast<float *>(ib + N);              // [8] wave sums of the pilot angles
+    unsigned *img = reinterpret_cast<unsigned *>(T + 64 * TS);   // [IMG_DW] the symbol's packed output image
+    float *red = reinterpret_cast<float *>(img + 1024);          // [8] wave sums of the pilot angles
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -603,14 +605,13 @@ __global__ __launch_bounds__(512) void k_demod4096(Big4096Params p) {
     cf z[8];                                      // W4096^(b c), c = t + 8 q
 #pragma unroll
     for (int q = 0; q < 8; ++q) z[q] = p.tw[col * (t + 8 * q)];
-    int ord[8];                                   // data ordinal of bin c + 64 d (d = t + 8 q), -1 = null, -2 = pilot
+    int boff[8];                                  // bit offset of bin c + 64 d (d = t + 8 q) in the image, -1 = not a data bin
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int d = t + 8 * q, cls = carrier_class64(d, GUARD);
-        ord[q] = cls == 0 ? (GUARD ? data_classes_below64(d) : d) * 64 + col : (cls == 2 ? -2 : -1);
+        const int d = t + 8 * q;
+        boff[q] = carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * 64 + col) * BPS : -1;
     }
-    const int nd = GUARD ? 48 * 64 : N;
-    const int nbytes = nd * p.bps / 8;
+    constexpr int nbytes = ND * BPS / 8;
 
     auto fetch = [&](long long sg, cf *dst) {
         if (sg < p.total) {
@@ -624,8 +625,16 @@ __global__ __launch_bounds__(512) void k_demod4096(Big4096Params p) {
             for (int m = 0; m < 8; ++m) dst[m] = make_float2(0.f, 0.f);
         }
     };
+    // The image of symbol j is stored to HBM at the top of iteration j + 1, right after that iteration's samples have
+    // been taken out of the prefetch registers: loads and stores share the in-order VM counter, so stores issued just
+    // before the next wait-for-loads would be waited for as well.
+    auto flush = [&](unsigned *dst) { // image -> global, and clear it for the next symbol (same thread, same dwords)
+        for (int i = tid; i < IMG_DW; i += 512) { dst[i] = img[i]; img[i] = 0u; }
+    };
+    for (int i = tid; i < IMG_DW; i += 512) img[i] = 0u;
     cf pre[8];
     fetch(blockIdx.x, pre);
+    unsigned *pending = nullptr; // where the image currently in LDS belongs
 
     for (long long sg = blockIdx.x; sg < p.total; sg += gridDim.x) {
         const long long f = sg / p.syms_per_frame;
@@ -634,6 +643,8 @@ __global__ __launch_bounds__(512) void k_demod4096(Big4096Params p) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = pre[m];
         fetch(sg + gridDim.x, pre);
+        if (pending) flush(pending);
+        pending = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes);
         // ---- stage A: FFT64 over a (wave-local)
         bfly8<false>(v);
 #pragma unroll
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(512) void k_demod4096(Big4096Params p) {
         // v[q] = Y_b[c = t + 8 q]; twiddle and transpose
 #pragma unroll
         for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + col] = cmul(v[q], z[q]);
-        __syncthreads();
+        __syncthreads(); // T complete; the image is clear
         // ---- stage B: FFT64 over b for row c = col
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = T[col * TS + t + 8 * m];
@@ -690,27 +701,21 @@ __global__ __launch_bounds__(512) void k_demod4096(Big4096Params p) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
         }
-        // demodulate (src/receiver.rs:147-190): hard decision per data bin -> LDS in ordinal order
+        // demodulate (src/receiver.rs:147-190) and pack LSB-first (src/utils.rs:30-36): OR every field into the image
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (ord[q] >= 0) ib[ord[q]] = (unsigned char)demap_point(v[q], p.bps);
-        __syncthreads();
-        {   // pack bps-bit indices LSB-first into bytes (src/utils.rs:30-36), whole dwords
-            unsigned *dst = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes);
-            for (int wd = tid; wd < nbytes / 4; wd += 512) {
-                unsigned acc = 0;
-                int i = (32 * wd) / p.bps;
-                for (;; ++i) {
-                    const int sh = i * p.bps - 32 * wd;
-                    if (sh >= 32) break;
-                    const unsigned val = ib[i];
-                    acc |= sh >= 0 ? (val << sh) : (val >> (-sh));
+        for (int q = 0; q < 8; ++q) {
+            if (boff[q] >= 0) {
+                const unsigned idx = demap_point(v[q], BPS);
+                const int wd = boff[q] >> 5, sh = boff[q] & 31;
+                atomicOr(&img[wd], idx << sh);
+                if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)
+                    if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
                 }
-                dst[wd] = acc;
             }
         }
-        __syncthreads(); // ib / T / red are reused by the next symbol
+        __syncthreads(); // image complete; T / red are reused by the next symbol
     }
+    if (pending) flush(pending);
 }
 
 // N = 4096 RX demod fast path.  hipErrorNotSupported => caller uses k_sym<4096, M_DEMOD>.
@@ -727,16 +732,26 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.bps = sp.bps; p.guard = sp.guard;
     if (p.total <= 0) return hipSuccess;
     const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64;
-    {   // > 64 KB of dynamic LDS: per device, so set on every call (one process may drive several GPUs); once per batch
-        hipError_t e = sp.guard ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_demod4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                : hipFuncSetAttribute(reinterpret_cast<const void *>(k_demod4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
     long long grid = (long long)num_cu * 2;
     if (grid > p.total) grid = p.total;
-    if (sp.guard) hipLaunchKernelGGL(k_demod4096<true>, dim3((unsigned)grid), dim3(512), lds, st, p);
-    else hipLaunchKernelGGL(k_demod4096<false>, dim3((unsigned)grid), dim3(512), lds, st, p);
-    return hipGetLastError();
+    // > 64 KB of dynamic LDS: a per-device attribute, so set on every call (one process may drive several GPUs); once per batch
+#define OFDM_LAUNCH_4096(B, G)                                                                                              \
+    {                                                                                                                       \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_demod4096<B, G>),                               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        if (e != hipSuccess) return e;                                                                                      \
+        hipLaunchKernelGGL((k_demod4096<B, G>), dim3((unsigned)grid), dim3(512), lds, st, p);                               \
+        return hipGetLastError();                                                                                           \
+    }
+    switch (sp.bps * 2 + (sp.guard ? 1 : 0)) {
+    case 2: OFDM_LAUNCH_4096(1, false) case 3: OFDM_LAUNCH_4096(1, true)
+    case 4: OFDM_LAUNCH_4096(2, false) case 5: OFDM_LAUNCH_4096(2, true)
+    case 8: OFDM_LAUNCH_4096(4, false) case 9: OFDM_LAUNCH_4096(4, true)
+    case 12: OFDM_LAUNCH_4096(6, false) case 13: OFDM_LAUNCH_4096(6, true)
+    case 16: OFDM_LAUNCH_4096(8, false) case 17: OFDM_LAUNCH_4096(8, true)
+    }
+#undef OFDM_LAUNCH_4096
+    return hipErrorNotSupported;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
