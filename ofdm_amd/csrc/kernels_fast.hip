@@ -1000,15 +1000,18 @@ __global__ __launch_bounds__(512) void k_tx4096(Tx4096Params p) {
         if (4 * tid < sym_bytes) d0 = dword(base + 4 * tid);
         if (4 * (tid + 512) < sym_bytes) d1 = dword(base + 4 * (tid + 512));
     };
+    // The bytes of symbol j+1 are taken out of the prefetch registers (and symbol j+2's loads issued) BEFORE symbol j's
+    // samples are stored: loads and stores share the in-order VM counter, so a wait for prefetched loads placed after the
+    // stores would wait for the stores as well.
     unsigned d0, d1;
     fetch(blockIdx.x, d0, d1);
+    sbw[tid] = d0;
+    sbw[tid + 512] = d1;
+    if (tid < 2) sbw[1024 + tid] = 0u; // slack for the two-byte window
+    fetch((long long)blockIdx.x + gridDim.x, d0, d1);
+    __syncthreads();
 
     for (long long sg = blockIdx.x; sg < p.n_sym; sg += gridDim.x) {
-        sbw[tid] = d0;
-        sbw[tid + 512] = d1;
-        if (tid < 2) sbw[1024 + tid] = 0u; // slack for the two-byte window
-        fetch(sg + gridDim.x, d0, d1);
-        __syncthreads();
         long long left = p.n_bytes - sg * sym_bytes;             // stream bytes that belong to this symbol
         left = left < 0 ? 0 : (left < sym_bytes ? left : sym_bytes);
         const int live_bits = (int)(((left * 8 + p.bps - 1) / p.bps) * p.bps); // fields that carry stream bits; the rest are 0
@@ -1046,6 +1049,9 @@ __global__ __launch_bounds__(512) void k_tx4096(Tx4096Params p) {
         for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
         bfly8<true>(v);
         // v[q] = N x[col + 64 (t + 8 q)]; prefix_block: out = [x[N - CP .. N), x[0 .. N)]
+        sbw[tid] = d0;               // next symbol's bytes (every wavefront left the mapping stage two barriers ago)
+        sbw[tid + 512] = d1;
+        fetch(sg + 2 * (long long)gridDim.x, d0, d1);
         cf *dst = p.out + sg * S;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
