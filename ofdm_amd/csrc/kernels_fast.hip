@@ -779,12 +779,14 @@ struct RxFrame1024Params {
     int bps;
 };
 
-template <bool GUARD>
+template <int BPS, bool GUARD>
 __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
     constexpr int N = 1024, S = 1280, CP = 256, TS = 72, SLAB = 8 * 72;
     __shared__ cf slab_all[2 * SLAB];
     __shared__ cf T[16 * TS];
-    __shared__ unsigned char ib[N];
+    constexpr int ND = GUARD ? 48 * 16 : N;
+    constexpr int IMG_DW = ND * BPS / 32;            // packed bytes of one symbol, in dwords (<= 256)
+    __shared__ unsigned img[256];                    // the symbol's packed output image (bit fields OR-ed in)
     __shared__ float red[2];
     __shared__ cf ztab[8 * 128];  // [c'][thread]: W16^(u c') * ... stage-A twiddles, loop-invariant, kept out of the VGPRs
     __shared__ cf w16tab[8 * 2];
@@ -805,12 +807,15 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
     if (tid < 16) w16tab[tid] = (tid & 1) ? p.tw[64 * (tid >> 1)] : make_float2(1.f, 0.f);
     if (tid < 56) w64tab[tid] = p.tw[16 * (tid / 8 + 1) * (tid & 7)];
     __syncthreads();
-    auto ordinal = [&](int q) -> int { // data ordinal of bin row + 16 d (d = t + 8 q), -1 = not a data bin
+    auto bitoff = [&](int q) -> int { // bit offset of bin row + 16 d (d = t + 8 q) in the image, -1 = not a data bin
         const int d = t + 8 * q;
-        return carrier_class64(d, GUARD) == 0 ? (GUARD ? data_classes_below64(d) : d) * 16 + row : -1;
+        return carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * 16 + row) * BPS : -1;
     };
-    const int nd = GUARD ? 48 * 16 : N;
-    const int nbytes = nd * p.bps / 8;
+    constexpr int nbytes = ND * BPS / 8;
+    // image -> global one symbol late (loads and stores share the in-order VM counter: stores issued just before the
+    // wait for the prefetched samples would be waited for too), clearing it for the next symbol
+    auto flush = [&](unsigned *dst) { for (int i = tid; i < IMG_DW; i += 128) { dst[i] = img[i]; img[i] = 0u; } };
+    for (int i = tid; i < 256; i += 128) img[i] = 0u;
 
     for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
         const int ns = p.nsym[f];
@@ -827,6 +832,7 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         };
         cf pre[8];
         fetch(5, pre);
+        unsigned *pending = nullptr; // where the image currently in LDS belongs
         cf g[8]; // first the spectrum sum of the training blocks, then 1 / H
 #pragma unroll
         for (int q = 0; q < 8; ++q) g[q] = make_float2(0.f, 0.f);
@@ -837,6 +843,7 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = pre[m];
             if (k + 1 < ns) fetch(chunk + 1, pre);
+            if (pending) { flush(pending); pending = nullptr; }
             if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50)
                 cf ph = cfo_phasor(turns, (long long)chunk * S + CP + 64 * u + b);
 #pragma unroll
@@ -901,27 +908,22 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
                 for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int o = ordinal(q);
-                if (o >= 0) ib[o] = (unsigned char)demap_point(v[q], p.bps);
-            }
-            __syncthreads();
-            {
-                unsigned *dst = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes);
-                for (int wd = tid; wd < nbytes / 4; wd += 128) {
-                    unsigned acc = 0;
-                    int i = (32 * wd) / p.bps;
-                    for (;; ++i) {
-                        const int sh = i * p.bps - 32 * wd;
-                        if (sh >= 32) break;
-                        const unsigned val = ib[i];
-                        acc |= sh >= 0 ? (val << sh) : (val >> (-sh));
+            for (int q = 0; q < 8; ++q) { // demodulate + LSB-first packing: OR every field into the image
+                const int bo = bitoff(q);
+                if (bo >= 0) {
+                    const unsigned idx = demap_point(v[q], BPS);
+                    const int wd = bo >> 5, sh = bo & 31;
+                    atomicOr(&img[wd], idx << sh);
+                    if (BPS > 1 && (32 % BPS) != 0) {
+                        if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
                     }
-                    dst[wd] = acc;
                 }
             }
-            __syncthreads(); // ib / T / red are reused by the next symbol
+            pending = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes);
+            __syncthreads(); // image complete; T / red are reused by the next symbol
         }
+        if (pending) flush(pending);
+        __syncthreads(); // the image is clear before the next frame ORs into it
     }
 }
 
@@ -937,9 +939,16 @@ hipError_t run_rxframe1024(const SymParams &sp, float2 *hk_out, hipStream_t st, 
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.hk = hk_out; p.bps = sp.bps;
     long long grid = (long long)num_cu * 7;
     if (grid > p.n_frames) grid = p.n_frames;
-    if (sp.guard) hipLaunchKernelGGL(k_rxframe1024<true>, dim3((unsigned)grid), dim3(128), 0, st, p);
-    else hipLaunchKernelGGL(k_rxframe1024<false>, dim3((unsigned)grid), dim3(128), 0, st, p);
-    return hipGetLastError();
+#define OFDM_LAUNCH_RX1024(B, G) { hipLaunchKernelGGL((k_rxframe1024<B, G>), dim3((unsigned)grid), dim3(128), 0, st, p); return hipGetLastError(); }
+    switch (sp.bps * 2 + (sp.guard ? 1 : 0)) {
+    case 2: OFDM_LAUNCH_RX1024(1, false) case 3: OFDM_LAUNCH_RX1024(1, true)
+    case 4: OFDM_LAUNCH_RX1024(2, false) case 5: OFDM_LAUNCH_RX1024(2, true)
+    case 8: OFDM_LAUNCH_RX1024(4, false) case 9: OFDM_LAUNCH_RX1024(4, true)
+    case 12: OFDM_LAUNCH_RX1024(6, false) case 13: OFDM_LAUNCH_RX1024(6, true)
+    case 16: OFDM_LAUNCH_RX1024(8, false) case 17: OFDM_LAUNCH_RX1024(8, true)
+    }
+#undef OFDM_LAUNCH_RX1024
+    return hipErrorNotSupported;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
