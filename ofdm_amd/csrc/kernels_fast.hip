@@ -1061,13 +1061,21 @@ __global__ __launch_bounds__(512) void k_tx4096(Tx4096Params p) {
         sbw[tid] = d0;               // next symbol's bytes (every wavefront left the mapping stage two barriers ago)
         sbw[tid + 512] = d1;
         fetch(sg + 2 * (long long)gridDim.x, d0, d1);
-        cf *dst = p.out + sg * S;
+        // transpose once more through T ([n >> 6][n & 63], the conflict-free layout of the first transpose) so that every
+        // store is a full 16 bytes per lane and 1 KiB per wavefront
+        __syncthreads(); // every wavefront has read its stage-B inputs out of T
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int n = col + 64 * (t + 8 * q);
-            const cf y = make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N));
-            dst[CP + n] = y;
-            if (n >= N - CP) dst[n - (N - CP)] = y;
+        for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + col] = make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N));
+        __syncthreads();
+        {
+            float4 *dst4 = reinterpret_cast<float4 *>(p.out + sg * S);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = tid + 512 * j, n = 2 * i;                      // sample pair (n, n + 1)
+                const float4 y = *reinterpret_cast<const float4 *>(T + (n >> 6) * TS + (n & 63));
+                dst4[(CP >> 1) + i] = y;
+                if (j == 3) dst4[i - ((N - CP) >> 1)] = y;                   // n >= N - CP: the cyclic prefix
+            }
         }
         __syncthreads(); // sbw / T are reused by the next symbol
     }
