@@ -173,6 +173,33 @@ def test_rx_demod_with_channel_and_tail_padding(api, orc):
     assert bytes(host(out_p).ravel()) == orc.rx_demod(wide(xp), n, True, mod)
 
 
+@pytest.mark.parametrize("n,mod,guard", [(4096, 4, True), (4096, 6, False), (64, 4, True), (1024, 6, True)])
+def test_rx_demod_equalised_fast_kernels(api, orc, n, mod, guard):
+    """rx_demod with a channel (equalise, receiver.rs:68-70) through the shape-specialised kernels (k_demod64 with a shared
+    channel, k_demod4096 with a shared and a per-frame channel) and the generic one (N = 1024), without soft output so
+    that the fast paths are taken: bytes against the oracle's, differing decisions excused only at a boundary."""
+    rng = np.random.default_rng(n + mod)
+    nsym = 8 if n == 64 else 3
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    S = ctx.S
+    frames, wants, softs, hks = [], [], [], []
+    for f in range(2):
+        x, _ = make_symbols(orc, rng, nsym, n, guard, mod, snr_db=33.0)
+        hk = fc32(1.0 + 0.25 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)))
+        frames.append(x); hks.append(hk)
+    xs = np.stack(frames)
+    # shared channel
+    out = host(ctx.rx_demod(dev(ctx, xs), nsym, hk=dev(ctx, hks[0])))
+    for f in range(2):
+        want, wsoft = orc.rx_demod(wide(xs[f]), n, guard, mod, hk=wide(hks[0]), want_soft=True)
+        assert_bytes_match(bytes(out[f]), want, wsoft, mod, what=f"shared hk, frame {f}")
+    # one channel per frame
+    out = host(ctx.rx_demod(dev(ctx, xs), nsym, hk=dev(ctx, np.stack(hks))))
+    for f in range(2):
+        want, wsoft = orc.rx_demod(wide(xs[f]), n, guard, mod, hk=wide(hks[f]), want_soft=True)
+        assert_bytes_match(bytes(out[f]), want, wsoft, mod, what=f"per-frame hk, frame {f}")
+
+
 # ------------------------------------------------------------------ EXT-3: Schmidl-Cox, a14, a15, a16
 def make_capture(orc, rng, mod, guard, payload, span, delay, fd, snr_db=30.0, n_fft=64):
     tx = orc.encode(payload, guard, mod, n_fft)
