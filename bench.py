@@ -32,7 +32,57 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the config-3 (full RX chain / Schmidl-Cox) report")
     ap.add_argument("--cfg3-frames", type=int, default=262_144)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction plumbing only: no GPU work, value null (CPU tests)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` started plainly (no torchrun): become the launcher.  The parent never touches the GPU
+    (no HIP call, no torch.cuda call): it builds libofdm_hip.so once (so the ranks never race hipcc; the build is
+    file-locked as well), starts N fresh child processes -- one rank per GPU, env as torchrun would set it -- relays
+    rank 0's JSON line and exits non-zero if any rank fails.  Children are plain `python bench.py ...` processes: no
+    re-exec of a process that has initialised the GPU."""
+    import subprocess
+
+    if not a.dry_run:
+        from ofdm_amd import build as hip_build
+
+        hip_build.build()
+    port = free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, WORLD_SIZE=str(a.gpus), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()  # rank 0 prints the one JSON line (after the closing barrier)
+    rc = 0
+    deadline = time.time() + 120
+    for p in procs:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the PID started above
+            p.wait()
+        rc = rc or p.returncode
+    json_lines = [ln for ln in out0.splitlines() if ln.lstrip().startswith("{")]
+    for ln in out0.splitlines():  # library chatter on rank 0's stdout (gloo / RCCL banners) goes to stderr: stdout carries ONE JSON line
+        if ln not in json_lines and ln.strip():
+            print(ln, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1], flush=True)
+    if rc != 0 or not json_lines:
+        print(f"bench.py: a rank failed (exit codes {[p.returncode for p in procs]})", file=sys.stderr)
+        sys.exit(rc or 1)
 
 
 def synth_cfg2(ctx, torch, n_frames, syms, snr_db, seed):
@@ -83,8 +133,39 @@ def cpu_baseline_cfg2(x_host, syms, n_threads):
     return F * syms * 80 / dt / 1e6, dt, outs
 
 
+def dry_run(a):
+    """The N-rank plumbing without the GPU: rendezvous, barrier, max / sum reductions, one JSON line from rank 0."""
+    from ofdm_amd.dist import Group
+
+    grp = Group()
+    if grp.world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but {grp.world} rank(s) came up", file=sys.stderr)
+        sys.exit(3)
+    grp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.001 * (grp.rank + 1))
+    grp.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = grp.gather_floats(dt * 1e3 / a.steps)
+    (dt,) = grp.reduce_max(dt)
+    (ranks,) = grp.reduce_sum(1.0)
+    if grp.rank == 0:
+        print(json.dumps({"metric": "complex IQ Msamples/s through RX demod", "value": None, "unit": "Msamples/s",
+                          "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps,
+                          "dry_run": True, "ranks_seen": int(ranks), "world_size_seen": grp.world,
+                          "backend": grp.backend, "ms_per_step_per_rank": per_rank}))
+    grp.close()
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a)
+    if a.dry_run:
+        return dry_run(a)
     import numpy as np
     import torch
 
@@ -96,8 +177,13 @@ def main():
         local = int(os.environ["OFDM_FORCE_DEVICE"])
     dist = grp.dist
     n_gpus = world
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if a.gpus != world:  # a silent N=1 number under an N-GPU label is worse than no number
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        grp.close()
+        sys.exit(3)
+    if local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} device(s) are visible", file=sys.stderr)
+        sys.exit(4)
     torch.cuda.set_device(local)
 
     from ofdm_amd import api

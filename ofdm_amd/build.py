@@ -37,7 +37,33 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+class _BuildLock:
+    """Exclusive advisory lock on csrc/_obj/.build.lock: N ranks importing the package at once (bench.py --gpus N,
+    torchrun) must never run hipcc into the same _obj/*.o / libofdm_hip.so concurrently.  The first rank builds, the
+    others block here and then find everything up to date."""
+
+    def __enter__(self):
+        import fcntl
+
+        os.makedirs(OBJ, exist_ok=True)
+        self.fd = os.open(os.path.join(OBJ, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+
+        fcntl.flock(self.fd, fcntl.LOCK_UN)
+        os.close(self.fd)
+        return False
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    with _BuildLock():
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -61,7 +87,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        tmp = LIB + f".tmp{os.getpid()}"  # link beside the target, then rename: a reader never sees a half-written .so
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs])
+        os.replace(tmp, LIB)
     return LIB
 
 

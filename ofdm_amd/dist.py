@@ -33,6 +33,7 @@ class Group:
         self.world, self.rank, self.local = env_world()
         self.dist = None
         self.device = device
+        self.backend = None
         if self.world > 1:
             import torch.distributed as dist
 
@@ -48,6 +49,7 @@ class Group:
             if not dist.is_initialized():
                 dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
+            self.backend = backend
         if self.device is None:
             self.device = torch.device("cpu")
 
@@ -68,6 +70,15 @@ class Group:
         if self.dist is None:
             return list(vals)
         t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t]
+
+    def gather_floats(self, val: float):
+        """Every rank's value in rank order, on every rank (per-rank step times in the bench report)."""
+        if self.dist is None:
+            return [float(val)]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.device)
+        t[self.rank] = float(val)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [float(v) for v in t]
 
