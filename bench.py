@@ -212,7 +212,16 @@ def main():
     ev_ms = ctx.timer_stop_ms()  # HIP events on the launch stream, spans exactly the K launches
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = grp.gather_floats(ev_ms / a.steps)  # every rank's own kernel time per step
     dt, ev_ms = grp.reduce_max(dt, ev_ms)  # the slowest rank defines the step time
+    solo_ms = None
+    if n_gpus > 1:  # the N = 1 reference of THIS run: rank 0 repeats the K steps alone while the others idle at a barrier
+        if rank == 0:
+            ctx.timer_start()
+            for _ in range(a.steps):
+                step()
+            solo_ms = ctx.timer_stop_ms() / a.steps
+        barrier()
 
     # parity at full size through a size-independent property: decoded bytes == transmitted payload (BER)
     nerr = int((out != payload).any(dim=1).sum())
@@ -245,7 +254,11 @@ def main():
                    "frames_per_gpu": F, "symbols_per_frame": syms, "samples_per_frame": syms * ctx.S,
                    "snr_db": a.snr_db, "parallelism": f"frame-index split x{n_gpus}, no collective"},
         "ber_vs_tx_payload": ber, "frames_with_errors": nerr, "roofline": roof,
+        "world_size_seen": world, "backend": grp.backend, "kernel_ms_per_rank": per_rank_ms,
     }
+    if solo_ms:  # informational (the driver computes scaling from its own N = 1 run): N ranks' aggregate over N x rank 0 alone
+        res["in_run_single_rank_kernel_ms"] = solo_ms
+        res["weak_scaling_efficiency_in_run"] = (n_gpus * samples_per_step / (dt / a.steps)) / (n_gpus * samples_per_step / (solo_ms / 1e3))
 
     if rank == 0 and n_gpus == 1 and not a.no_cpu:
         ncores = os.cpu_count() or 1

@@ -736,11 +736,10 @@ __global__ __launch_bounds__(256) void k_freq_corr(const cf *in, long long n_pai
     if (pidx >= n_pairs) return;
     const cf *l = in + pidx * stride, *r = l + right_offset;
     double sum = 0.0;
-    for (int m = lane; m < L; m += 64) {
-        cf q = cmulc(r[m], l[m]);            // angle(r / l) == angle(r * conj(l))
-        cf a = l[m];
-        float ns = a.x * a.x + a.y * a.y;    // the reference divides first (num-complex Div)
-        sum += (double)atan2f(q.y / ns, q.x / ns);
+    for (int m = lane; m < L; m += 64) {    // all f64 like the reference (receiver.rs:231-240): products of f32 are exact
+        const double lr = l[m].x, li = l[m].y, rr = r[m].x, ri = r[m].y;
+        const double ns = lr * lr + li * li; // the reference divides first (num-complex Div): r / l = r conj(l) / |l|^2
+        sum += atan2((ri * lr - rr * li) / ns, (rr * lr + ri * li) / ns);
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s, 64);

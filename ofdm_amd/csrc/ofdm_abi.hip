@@ -84,6 +84,19 @@ struct ofdm_ctx {
     int bytes_per_symbol() const { return carriers() * prm.modulation / 8; }
 };
 
+// Scoped device selection: every entry point that touches HIP runs on its context's device and leaves the calling
+// thread's current device as it found it (one thread may hold contexts on several GPUs; torch shares the thread's device).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 #define HIP_TRY(ctx, expr)                                   \
     do {                                                     \
         hipError_t _e = (expr);                              \
@@ -260,6 +273,8 @@ int ofdm_chacha_block(const uint32_t *key8, const uint32_t *words12_15, int32_t 
 
 int ofdm_destroy(ofdm_ctx *c) {
     if (!c) return OFDM_OK;
+    int prev_dev = -1;
+    const bool have_prev = hipGetDevice(&prev_dev) == hipSuccess;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &w : c->ws) if (w.ptr) hipFree(w.ptr);
@@ -270,6 +285,7 @@ int ofdm_destroy(ofdm_ctx *c) {
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
+    if (have_prev) hipSetDevice(prev_dev);
     return OFDM_OK;
 }
 
@@ -293,7 +309,7 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return OFDM_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) return OFDM_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return OFDM_ERR_NO_DEVICE;
+    DeviceGuard dev_guard(device); // the caller's current device is restored on every return path
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return OFDM_ERR_NO_DEVICE;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return OFDM_ERR_NO_DEVICE; // gfx950 code objects only
@@ -354,12 +370,14 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
 
 int ofdm_set_stream(ofdm_ctx *c, void *stream) {
     if (!c) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->own_stream = false; }
     c->stream = (hipStream_t)stream;
     return OFDM_OK;
 }
 int ofdm_synchronize(ofdm_ctx *c) {
     if (!c) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return OFDM_OK;
 }
@@ -367,29 +385,33 @@ int ofdm_last_hip_error(const ofdm_ctx *c) { return c ? c->last_hip : 0; }
 
 int ofdm_dev_alloc(ofdm_ctx *c, size_t bytes, void **dev) {
     if (!c || !dev) return OFDM_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
     hipError_t e = hipMalloc(dev, bytes ? bytes : 1);
     if (e != hipSuccess) { c->last_hip = (int)e; *dev = nullptr; return OFDM_ERR_NOMEM; }
     return OFDM_OK;
 }
 int ofdm_dev_free(ofdm_ctx *c, void *dev) {
     if (!c) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (dev) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(dev)); }
     return OFDM_OK;
 }
 int ofdm_memcpy_h2d(ofdm_ctx *c, void *dev, const void *host, size_t bytes) {
     if (!c || (bytes && (!dev || !host))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
     return OFDM_OK;
 }
 int ofdm_memcpy_d2h(ofdm_ctx *c, void *host, const void *dev, size_t bytes) {
     if (!c || (bytes && (!dev || !host))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return OFDM_OK;
 }
 int ofdm_memset(ofdm_ctx *c, void *dev, int value, size_t bytes) {
     if (!c || (bytes && !dev)) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, hipMemsetAsync(dev, value, bytes, c->stream));
     return OFDM_OK;
 }
@@ -414,6 +436,7 @@ int64_t ofdm_frame_samples(const ofdm_ctx *c, int64_t payload_bytes) {
 // ------------------------------------------------------------------ stage level
 int ofdm_fft_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_t n_vec, int inverse) {
     if (!c || n_vec < 0 || (n_vec && (!in || !out))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     SymParams p = base_params(c);
     const int N = c->prm.n_fft;
     p.in = reinterpret_cast<const float2 *>(in); p.out = reinterpret_cast<float2 *>(out);
@@ -423,6 +446,7 @@ int ofdm_fft_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_t n_v
 }
 int ofdm_ifft_cp_batch(ofdm_ctx *c, const ofdm_fc32 *freq, ofdm_fc32 *out, int64_t n_sym) {
     if (!c || n_sym < 0 || (n_sym && (!freq || !out))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     SymParams p = base_params(c);
     const int N = c->prm.n_fft;
     p.in = reinterpret_cast<const float2 *>(freq); p.out = reinterpret_cast<float2 *>(out);
@@ -435,6 +459,7 @@ int ofdm_tx_symbols_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, of
     const int bps_bytes = c->bytes_per_symbol();
     if (n_sym * (int64_t)bps_bytes < n_bytes) return OFDM_ERR_INVALID; // every byte must land in a symbol
     if (!n_sym) return OFDM_OK;
+    DeviceGuard dev_guard(c->device);
     SymParams p = base_params(c);
     p.n_frames = n_sym; p.syms_per_frame = 1;
     p.payload = bytes; p.payload_stride = bps_bytes; p.payload_len = nullptr; p.payload_bytes = bps_bytes;
@@ -451,6 +476,7 @@ int ofdm_tx_symbols_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, of
 }
 int ofdm_unprefix_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_t n_sym) {
     if (!c || n_sym < 0 || (n_sym && (!in || !out))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     SymParams p = base_params(c);
     const int N = c->prm.n_fft, S = c->S();
     p.in = reinterpret_cast<const float2 *>(in); p.out = reinterpret_cast<float2 *>(out);
@@ -460,23 +486,27 @@ int ofdm_unprefix_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_
 }
 int ofdm_qam_map_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, ofdm_fc32 *out) {
     if (!c || n_bytes < 0 || (n_bytes && (!bytes || !out))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, run_qam_map(bytes, n_bytes, c->prm.modulation, reinterpret_cast<float2 *>(out), c->stream));
     return OFDM_OK;
 }
 int ofdm_qam_demap_batch(ofdm_ctx *c, const ofdm_fc32 *sym, int64_t n_sym, uint8_t *bytes, uint8_t *idx) {
     if (!c || n_sym < 0 || (n_sym && !sym)) return OFDM_ERR_INVALID;
     if (n_sym % 8 != 0) return OFDM_ERR_INVALID; // assert_eq!(remainder.len(), 0), src/receiver.rs:153
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, run_qam_demap(reinterpret_cast<const float2 *>(sym), n_sym, c->prm.modulation, bytes, idx, c->stream));
     return OFDM_OK;
 }
 int ofdm_encode_block_batch(ofdm_ctx *c, const ofdm_fc32 *data, ofdm_fc32 *bins, int64_t n_sym) {
     if (!c || n_sym < 0 || (n_sym && (!data || !bins))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, run_encode_block(reinterpret_cast<const float2 *>(data), reinterpret_cast<float2 *>(bins), n_sym,
                                 c->prm.n_fft, c->prm.guard_bands, c->stream));
     return OFDM_OK;
 }
 int ofdm_normalize_batch(ofdm_ctx *c, ofdm_fc32 *x, int64_t n_frames, int64_t frame_stride, int64_t frame_len) {
     if (!c || n_frames < 0 || frame_len < 0 || frame_stride < frame_len || (n_frames && !x)) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (!n_frames) return OFDM_OK;
     void *mx;
     int rc = ws_get(c, 0, sizeof(unsigned) * (size_t)n_frames, &mx);
@@ -488,11 +518,13 @@ int ofdm_normalize_batch(ofdm_ctx *c, ofdm_fc32 *x, int64_t n_frames, int64_t fr
 }
 int ofdm_hamming74_encode(ofdm_ctx *c, const uint8_t *in, int64_t n_bytes, uint8_t *out) {
     if (!c || n_bytes < 0 || (n_bytes && (!in || !out))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, run_ham_encode(in, 1, 0, nullptr, n_bytes, out, 0, nullptr, c->stream));
     return OFDM_OK;
 }
 int ofdm_hamming74_decode(ofdm_ctx *c, const uint8_t *in, int64_t n_bytes, uint8_t *out, uint32_t *corrected) {
     if (!c || n_bytes < 0 || (n_bytes >= 7 && (!in || !out))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, run_ham_decode(in, n_bytes, out, corrected, c->stream));
     return OFDM_OK;
 }
@@ -548,23 +580,27 @@ int ofdm_sc_correlate_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, 
     if (!c || n_frames < 0 || frame_len <= 0 || frame_stride < 0 || (n_frames && (!in || !d_hat))) return OFDM_ERR_INVALID;
     if (n_frames > 1 && frame_stride <= 0) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
+    DeviceGuard dev_guard(c->device);
     return sc_run(c, reinterpret_cast<const float2 *>(in), n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric);
 }
 int ofdm_frequency_correction_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_pairs, int64_t stride,
                                     int64_t right_offset, double *f_delta) {
     if (!c || n_pairs < 0 || (n_pairs && (!in || !f_delta))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, run_freq_correction(reinterpret_cast<const float2 *>(in), n_pairs, stride, right_offset, c->S(), f_delta, c->stream));
     return OFDM_OK;
 }
 int ofdm_cfo_rotate_batch(ofdm_ctx *c, ofdm_fc32 *x, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
                           const double *f_delta, const int32_t *first_index) {
     if (!c || n_frames < 0 || frame_len < 0 || (n_frames && (!x || !f_delta))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, run_cfo_rotate(reinterpret_cast<float2 *>(x), n_frames, frame_stride, frame_len, f_delta, first_index, c->stream));
     return OFDM_OK;
 }
 int ofdm_estimate_channel_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int64_t frame_stride,
                                 int64_t frame_len, const int32_t *offset, const double *f_delta, ofdm_fc32 *hk) {
     if (!c || n_frames < 0 || frame_len <= 0 || (n_frames && (!in || !hk))) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     SymParams p = base_params(c);
     p.in = reinterpret_cast<const float2 *>(in); p.out = reinterpret_cast<float2 *>(hk);
     p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
@@ -605,6 +641,7 @@ int ofdm_rx_demod_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int6
     if (out_stride < (int64_t)syms_per_frame * c->bytes_per_symbol()) return OFDM_ERR_INVALID;
     if (hk && hk_stride != 0 && hk_stride != c->prm.n_fft) return OFDM_ERR_INVALID;
     if (!n_frames || !syms_per_frame) return OFDM_OK;
+    DeviceGuard dev_guard(c->device);
     return demod_run(c, reinterpret_cast<const float2 *>(in), n_frames, frame_stride, frame_len, first_symbol,
                      syms_per_frame, offset, f_delta, nullptr, reinterpret_cast<const float2 *>(hk), hk_stride, out,
                      out_stride, reinterpret_cast<float2 *>(soft));
@@ -618,6 +655,7 @@ int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, 
     const int64_t frame = ofdm_frame_samples(c, payload_bytes);
     if (out_stride < frame) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
+    DeviceGuard dev_guard(c->device);
     const int S = c->S();
     const uint8_t *src = payload; int64_t src_stride = payload_stride; const int32_t *src_len = payload_len;
     int32_t src_bytes = payload_bytes;
@@ -661,8 +699,12 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     if (n_frames > 1 && frame_stride <= 0) return OFDM_ERR_INVALID;
     const int bps_bytes = c->bytes_per_symbol();
     const int64_t raw_stride = (int64_t)max_symbols * bps_bytes;
-    if (out_stride < raw_stride - 16 && c->prm.ecc == OFDM_ECC_NONE) return OFDM_ERR_INVALID;
+    // rows must hold what k_rx_finish can write: the whole body without an outer code, floor(body / 7) * 4 bytes after
+    // Hamming(7,4) decoding (include/ofdm_hip.h)
+    const int64_t body_max = raw_stride > 16 ? raw_stride - 16 : 0;
+    if (out_stride < (c->prm.ecc == OFDM_ECC_NONE ? body_max : (body_max / 7) * 4)) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
+    DeviceGuard dev_guard(c->device);
     const int N = c->prm.n_fft;
     void *w_dhat, *w_fd, *w_off, *w_nsym, *w_hk, *w_raw;
     int rc;
@@ -724,11 +766,13 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
 
 int ofdm_timer_start(ofdm_ctx *c) {
     if (!c) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     return OFDM_OK;
 }
 int ofdm_timer_stop_ms(ofdm_ctx *c, float *ms) {
     if (!c || !ms) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));

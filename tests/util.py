@@ -46,6 +46,26 @@ def make_symbols(orc, rng, n_sym, n_fft, guard, mod, snr_db=30.0):
     return fc32(x), data
 
 
+def make_symbols_np(orc, rng, n_sym, n_fft, guard, mod, snr_db=30.0):
+    """make_symbols for large batches: the same construction (modulate -> encode_block -> prefix_block -> AWGN) with the
+    per-symbol oracle calls replaced by numpy array operations (the carrier map comes from the oracle's carrier_class,
+    the points from the oracle's modulate).  Only an INPUT generator: expected outputs always come from the oracle."""
+    nd = orc.data_carriers(n_fft, guard)
+    nbytes = n_sym * nd * mod // 8
+    data = bytes(rng.integers(0, 256, nbytes, dtype=np.uint8))
+    pts = np.asarray(orc.modulate(data, mod)).reshape(n_sym, nd)
+    cls = np.array([orc.carrier_class(i, n_fft, guard) for i in range(n_fft)])
+    bins = np.zeros((n_sym, n_fft), np.complex128)
+    bins[:, cls == 0] = pts
+    bins[:, cls == 2] = 1.0
+    t = np.fft.ifft(bins, axis=1)
+    cp = n_fft // 4
+    x = np.concatenate([t[:, n_fft - cp:], t], axis=1).reshape(-1)
+    p = np.mean(np.abs(x) ** 2)
+    x = x + awgn(rng, x.shape, np.sqrt(p / 10 ** (snr_db / 10) / 2))
+    return fc32(x), data
+
+
 def through_channel(orc, rng, tx, span, delay, f_delta, snr_db=30.0, taps=True, data_start=None):
     """Config-3 style capture: `delay` leading zeros, FIR CHANNEL (src/channel.rs:26-31), CFO
     exp(+j f (i+1)) (channel.rs:58-62), AWGN, cut/padded to `span` samples.
