@@ -250,4 +250,51 @@ __device__ __forceinline__ unsigned ham_dec(unsigned c, unsigned &fixed) {
     return c & 0xFu;
 }
 
+template <int CTRL> __device__ __forceinline__ float dpp8_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum8_lanes(float x) { // sum over the 8 lanes of a symbol group (lanes 8s .. 8s+7)
+    x += dpp8_f<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += dpp8_f<0x4E>(x);  // quad_perm [2,3,0,1]
+    x += dpp8_f<0x141>(x); // row_half_mirror
+    return x;
+}
+
+// ---- FFT64 with ONE point per lane (decimation in frequency, 6 radix-2 stages across the wavefront): lane n enters with
+// x[n] and leaves with X[bitrev6(n)].  ~12 VALU per stage instead of a whole 8-symbol group iteration, which is what
+// makes the per-frame channel estimate cheap (one transform per frame).  tws[st] = this lane's twiddle of stage st
+// (1 for the lanes that take the sum).
+template <int CTRL> __device__ __forceinline__ cf dpp_cf(cf v) { return make_float2(dpp8_f<CTRL>(v.x), dpp8_f<CTRL>(v.y)); }
+__device__ __forceinline__ cf lane_fft64(cf x, int lane, const cf *tws) {
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        const int h = 32 >> st;
+        cf xp;
+        if (h == 32) xp = make_float2(__shfl_xor(x.x, 32, 64), __shfl_xor(x.y, 32, 64));
+        else if (h == 16) xp = make_float2(__shfl_xor(x.x, 16, 64), __shfl_xor(x.y, 16, 64));
+        else if (h == 8) xp = dpp_cf<0x128>(x);                 // row_ror:8   : lane ^ 8
+        else if (h == 4) xp = dpp_cf<0x1B>(dpp_cf<0x141>(x));   // half mirror (^7) then quad reverse (^3) : lane ^ 4
+        else if (h == 2) xp = dpp_cf<0x4E>(x);                  // quad_perm [2,3,0,1] : lane ^ 2
+        else xp = dpp_cf<0xB1>(x);                              // quad_perm [1,0,3,2] : lane ^ 1
+        const float sg = (lane & h) ? -1.f : 1.f;              // lower half: a + b; upper half: (a - b) w
+        const cf y = make_float2(fmaf(sg, x.x, xp.x), fmaf(sg, x.y, xp.y));
+        x = cmul(y, tws[st]);
+    }
+    return x;
+}
+__device__ __forceinline__ int bitrev6(int v) { return (int)(__brev((unsigned)v) >> 26); }
+
+// one 7-byte block (8 codewords, LSB first) -> 4 data bytes
+__device__ __forceinline__ void ham_decode_block(const uint8_t *src, uint8_t *dst, unsigned &fixed) {
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc |= (unsigned long long)src[j] << (8 * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned lo = ham_dec((unsigned)(acc >> (14 * j)) & 0x7Fu, fixed);
+        unsigned hi = ham_dec((unsigned)(acc >> (14 * j + 7)) & 0x7Fu, fixed);
+        dst[j] = (uint8_t)(lo | (hi << 4));
+    }
+}
+
 } // namespace ofdm

@@ -67,8 +67,10 @@ hipError_t run_tx4096(const SymParams &p, hipStream_t st, int num_cu);
 // fused estimate_channel + per-symbol demod for N = 64 frames with per-frame offset / CFO / live-symbol count
 // final_out / final_stride / final_len (optional, 4-byte aligned): also do the length-header parse + truncate and write the
 // payload bytes to their final place (no outer code), so that no separate finish kernel is needed
+// frame_list / frame_count (device, optional): only the listed frames are processed
 hipError_t run_rxframe64(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu, unsigned char *final_out = nullptr,
-                         long long final_stride = 0, int32_t *final_len = nullptr);
+                         long long final_stride = 0, int32_t *final_len = nullptr, const int32_t *frame_list = nullptr,
+                         const int32_t *frame_count = nullptr);
 // fused encode for N = 64 (map + IFFT + CP + header + normalise, one HBM pass); hipErrorNotSupported outside its envelope
 hipError_t run_txframe64(const SymParams &p, const float2 *header, float header_max, hipStream_t st, int num_cu);
 
@@ -100,7 +102,21 @@ hipError_t run_sc(const ScParams &p, hipStream_t st);
 // fast path for one-tile frames with a short period (f32 filter + exact f64 decisions; kernels_sync.hip)
 bool sc_fast_ok(const ScParams &p);
 size_t sc_fast_workspace_bytes(long long n_frames, int W);
-hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st);
+// fused timing + receive body for N = 64 frames that fit one tile (k_sc_cf<..., BPS != 0>): one pass over HBM for the whole
+// decode.  Frames the f32 filter cannot settle stay on the slow list for the list-mode kernels below.
+struct ScRxFused {
+    int bps = 0, guard = 0, backoff = 0, cfo_mode = 0, max_symbols = 0, ecc = 0;
+    const float2 *tw = nullptr, *inv_training = nullptr;
+    const double *atan_tab = nullptr;
+    unsigned char *out = nullptr;
+    long long out_stride = 0;
+    int32_t *out_len = nullptr, *status = nullptr, *offset = nullptr;
+    double *f_delta = nullptr;
+    float *metric = nullptr;
+};
+bool sc_rx_fused_ok(const ScParams &p, const ScRxFused &rx);
+hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st, const ScRxFused *rx = nullptr,
+                       const int32_t **slow_list = nullptr, const int32_t **slow_count = nullptr);
 hipError_t run_sc_min_cross(const long long *cross, int tiles_per_frame, long long n_frames, int32_t *d1, hipStream_t st);
 hipError_t run_freq_correction(const float2 *in, long long n_pairs, long long stride, long long right_offset, int L,
                                double *f_delta, hipStream_t st);
@@ -124,10 +140,12 @@ hipError_t run_tx_finish(float2 *out, long long n_frames, long long out_stride, 
 // RX prepare: d_hat -> status / offset / live symbols / CFO (receiver.rs:21-39)
 hipError_t run_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_delta, long long frame_len, int L,
                           int backoff, int cfo_mode, int max_symbols, int bytes_per_symbol, int32_t *status,
-                          int32_t *offset, int32_t *nsym, hipStream_t st);
+                          int32_t *offset, int32_t *nsym, hipStream_t st, const int32_t *frame_list = nullptr,
+                          const int32_t *frame_count = nullptr);
 // RX finish: header parse + truncate [+ Hamming decode] (receiver.rs:85-95)
 hipError_t run_rx_finish(const uint8_t *raw, long long raw_stride, long long n_frames, const int32_t *status,
                          const int32_t *nsym, int bytes_per_symbol, int ecc, uint8_t *out, long long out_stride,
-                         int32_t *out_len, hipStream_t st);
+                         int32_t *out_len, hipStream_t st, const int32_t *frame_list = nullptr,
+                         const int32_t *frame_count = nullptr);
 
 } // namespace ofdm

@@ -142,17 +142,6 @@ hipError_t run_ham_encode(const uint8_t *in, long long n_frames, long long in_st
                        in_len, n_bytes, out, out_stride, out_len, bpf);
     return hipGetLastError();
 }
-__device__ __forceinline__ void ham_decode_block(const uint8_t *src, uint8_t *dst, unsigned &fixed) {
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) acc |= (unsigned long long)src[j] << (8 * j);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        unsigned lo = ham_dec((unsigned)(acc >> (14 * j)) & 0x7Fu, fixed);
-        unsigned hi = ham_dec((unsigned)(acc >> (14 * j + 7)) & 0x7Fu, fixed);
-        dst[j] = (uint8_t)(lo | (hi << 4));
-    }
-}
 __global__ __launch_bounds__(256) void k_ham_decode(const uint8_t *in, long long n_blocks, uint8_t *out,
                                                     uint32_t *corrected) {
     unsigned fixed = 0;
@@ -196,12 +185,9 @@ hipError_t run_tx_finish(float2 *out, long long n_frames, long long out_stride, 
 }
 
 // decode bookkeeping (src/receiver.rs:21-39): timing -> trimmed offset, length check, live symbol count
-__global__ __launch_bounds__(256) void k_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_delta,
-                                                    long long frame_len, int L, int backoff, int cfo_mode,
-                                                    int max_symbols, int bytes_per_symbol, int32_t *status,
-                                                    int32_t *offset, int32_t *nsym) {
-    long long f = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (f >= n_frames) return;
+__device__ __forceinline__ void rx_prepare_one(long long f, const int32_t *d_hat, double *f_delta, long long frame_len, int L,
+                                               int backoff, int cfo_mode, int max_symbols, int bytes_per_symbol,
+                                               int32_t *status, int32_t *offset, int32_t *nsym) {
     int st = 0, off = 0, ns = 0;
     const int d = d_hat[f];
     if (d < 0) st = -2; // OFDM_FRAME_NOSYNC
@@ -222,23 +208,42 @@ __global__ __launch_bounds__(256) void k_rx_prepare(long long n_frames, const in
     offset[f] = off;
     nsym[f] = st == 0 ? ns : 0;
 }
+__global__ __launch_bounds__(256) void k_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_delta,
+                                                    long long frame_len, int L, int backoff, int cfo_mode,
+                                                    int max_symbols, int bytes_per_symbol, int32_t *status,
+                                                    int32_t *offset, int32_t *nsym, const int32_t *frame_list,
+                                                    const int32_t *frame_count) {
+    if (frame_list) { // list mode (a single block): only the listed frames
+        for (long long i = threadIdx.x; i < (long long)*frame_count; i += 256)
+            rx_prepare_one(frame_list[i], d_hat, f_delta, frame_len, L, backoff, cfo_mode, max_symbols, bytes_per_symbol, status,
+                           offset, nsym);
+        return;
+    }
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f < n_frames)
+        rx_prepare_one(f, d_hat, f_delta, frame_len, L, backoff, cfo_mode, max_symbols, bytes_per_symbol, status, offset, nsym);
+}
 hipError_t run_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_delta, long long frame_len, int L,
                           int backoff, int cfo_mode, int max_symbols, int bytes_per_symbol, int32_t *status,
-                          int32_t *offset, int32_t *nsym, hipStream_t st) {
+                          int32_t *offset, int32_t *nsym, hipStream_t st, const int32_t *frame_list,
+                          const int32_t *frame_count) {
     if (n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rx_prepare, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, n_frames, d_hat,
-                       f_delta, frame_len, L, backoff, cfo_mode, max_symbols, bytes_per_symbol, status, offset, nsym);
+    hipLaunchKernelGGL(k_rx_prepare, dim3(frame_list ? 1u : (unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, n_frames, d_hat,
+                       f_delta, frame_len, L, backoff, cfo_mode, max_symbols, bytes_per_symbol, status, offset, nsym,
+                       frame_list, frame_count);
     return hipGetLastError();
 }
 
 // header parse + truncate (src/receiver.rs:85-95) [+ Hamming(7,4) decode]: one wavefront per frame
 __global__ __launch_bounds__(256) void k_rx_finish(const uint8_t *raw, long long raw_stride, long long n_frames,
                                                    const int32_t *status, const int32_t *nsym, int bytes_per_symbol,
-                                                   int ecc, uint8_t *out, long long out_stride, int32_t *out_len) {
+                                                   int ecc, uint8_t *out, long long out_stride, int32_t *out_len,
+                                                   const int32_t *frame_list, const int32_t *frame_count) {
     const int lane = threadIdx.x & 63;
-    const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= n_frames) return;
-    if (status[f] != 0) { if (lane == 0) out_len[f] = 0; return; }
+    const long long total = frame_list ? (long long)*frame_count : n_frames;
+  for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (long long)gridDim.x * 4) {
+    const long long f = frame_list ? (long long)frame_list[i] : i;
+    if (status[f] != 0) { if (lane == 0) out_len[f] = 0; continue; }
     const uint8_t *src = raw + f * raw_stride;
     const long long body = (long long)nsym[f] * bytes_per_symbol - 16;
     unsigned long long lo = 0, hi = 0; // bincode fixint little-endian u128 (src/packets/mod.rs:20-32)
@@ -268,13 +273,16 @@ __global__ __launch_bounds__(256) void k_rx_finish(const uint8_t *raw, long long
         for (long long b = lane; b < blocks; b += 64) ham_decode_block(src + 16 + b * 7, dst + b * 4, fixed);
         if (lane == 0) out_len[f] = (int32_t)(blocks * 4);
     }
+  }
 }
 hipError_t run_rx_finish(const uint8_t *raw, long long raw_stride, long long n_frames, const int32_t *status,
                          const int32_t *nsym, int bytes_per_symbol, int ecc, uint8_t *out, long long out_stride,
-                         int32_t *out_len, hipStream_t st) {
+                         int32_t *out_len, hipStream_t st, const int32_t *frame_list, const int32_t *frame_count) {
     if (n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rx_finish, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, st, raw, raw_stride, n_frames,
-                       status, nsym, bytes_per_symbol, ecc, out, out_stride, out_len);
+    long long blocks = (n_frames + 3) / 4;
+    if (frame_list && blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(k_rx_finish, dim3((unsigned)blocks), dim3(256), 0, st, raw, raw_stride, n_frames,
+                       status, nsym, bytes_per_symbol, ecc, out, out_stride, out_len, frame_list, frame_count);
     return hipGetLastError();
 }
 

@@ -165,6 +165,8 @@ struct RxFrame64Params {
     unsigned char *final_out;
     long long final_stride;
     int32_t *final_len;
+    const int32_t *frame_list;   // optional: only these frames (count on the device)
+    const int32_t *frame_count;
 };
 
 __device__ __forceinline__ cf lane_xor_sum(cf v) { // sum over the 8 symbol slots: lanes with equal (lane & 7)
@@ -202,7 +204,9 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
     }
     const int wr = swz(8 * t);
 
-    for (long long f = (long long)blockIdx.x * 4 + wave; f < p.n_frames; f += (long long)gridDim.x * 4) {
+    const long long n_items = p.frame_list ? (long long)*p.frame_count : p.n_frames;
+    for (long long item = (long long)blockIdx.x * 4 + wave; item < n_items; item += (long long)gridDim.x * 4) {
+        const long long f = p.frame_list ? (long long)p.frame_list[item] : item;
         const int ns = p.nsym[f];
         if (ns <= 0) { if (p.final_out && lane == 0) p.final_len[f] = 0; continue; } // wave-uniform
         const long long off = p.offset ? p.offset[f] : 0;
@@ -212,17 +216,50 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
         const cf *src = p.in + f * p.frame_stride + off;
         const long long avail = p.frame_len - off; // samples of the trimmed frame
 
-        // group -1 = the 5 training blocks (chunks 5..9) -> 1/H; groups 0.. = data symbols, 8 at a time (chunks 10..)
+        // estimate_channel (receiver.rs:212-229) on the 5 training blocks (chunks 5..9): H = mean_b FFT(block_b) / training
+        // = FFT(mean_b block_b) / training.  Lane n sums sample n of the 5 derotated blocks, the wavefront transforms the 64
+        // sums with one point per lane (lane_fft64), lane l then holds bin bitrev6(l): ONE transform per frame instead of a
+        // whole 8-symbol group iteration.  1/H goes through the wave's LDS slab into the (t + 8 m) register layout.
         cf g[8];
+        {
+            cf tws[6];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) g[m] = make_float2(1.f, 0.f);
-        for (int k0 = -8; k0 < ns; k0 += 8) {
-            const bool chest = k0 < 0;
-            const int count = chest ? 5 : (ns - k0 < 8 ? ns - k0 : 8);
-            const int n0 = ((chest ? 5 : 10 + k0) + s) * S + CP + t; // sample id of this lane's first point
+            for (int q = 0; q < 6; ++q) {
+                const int h = 32 >> q;
+                tws[q] = (lane & h) ? p.tw[(lane & (h - 1)) << q] : make_float2(1.f, 0.f);
+            }
+            const int nb = 5 * S + CP + lane;
+            cf xb[5];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) xb[b] = (nb + S * b) < avail ? src[nb + S * b] : make_float2(0.f, 0.f);
+            cf acc;
+            if (p.f_delta) { // sum_b x_b e^{-j phi (nb + 80 b)}: Horner in the 80-sample step, then this lane's phasor
+                const cf s80 = cfo_phasor(turns, S), q0 = cfo_phasor(turns, nb);
+                acc = cadd(cmul(xb[4], s80), xb[3]);
+                acc = cadd(cmul(acc, s80), xb[2]);
+                acc = cadd(cmul(acc, s80), xb[1]);
+                acc = cadd(cmul(acc, s80), xb[0]);
+                acc = cmul(acc, q0);
+            } else acc = cadd(cadd(cadd(xb[4], xb[3]), cadd(xb[2], xb[1])), xb[0]);
+            acc = lane_fft64(acc, lane, tws);
+            const int bin = bitrev6(lane);
+            cf h = cmul(acc, p.inv_training[bin]);                   // 64-entry table, L2/L1 resident
+            h = make_float2(h.x * 0.2f, h.y * 0.2f);
+            if (p.hk) p.hk[f * 64 + bin] = h;
+            const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
+            cf *slab = slab_all + wave * SLAB;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            slab[bin] = make_float2(h.x * rn, -h.y * rn);            // 1 / H
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int m = 0; m < 8; ++m) g[m] = slab[t + 8 * m];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        for (int k0 = 0; k0 < ns; k0 += 8) { // data symbols, 8 at a time (chunks 10..)
+            const int count = ns - k0 < 8 ? ns - k0 : 8;
+            const int n0 = (10 + k0 + s) * S + CP + t; // sample id of this lane's first point
             cf v[8];
-            const int first_chunk = chest ? 5 : 10 + k0;
-            const bool all_inside = (long long)(first_chunk + count) * S <= avail; // wave-uniform: no tail padding in this group
+            const bool all_inside = (long long)(10 + k0 + count) * S <= avail; // wave-uniform: no tail padding in this group
             if (s < count) {
                 if (all_inside) {
 #pragma unroll
@@ -248,29 +285,6 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             bfly8<false>(v);
-            if (chest) { // estimate_channel: H = mean_b FFT(block_b) / training  (receiver.rs:212-229)
-                // The five spectra meet in the wave's LDS slab; lane (s, t) then owns ONE bin, t + 8 s: it adds the five
-                // values, forms H and 1/H once (not once per symbol slot), and hands 1/H back through the slab.
-                cf *slab = slab_all + wave * SLAB;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-                for (int m = 0; m < 8; ++m) buf[t + 8 * m] = v[m];      // row s (rows 5..7 carry zeros)
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int bin = t + 8 * s;
-                cf acc = slab[bin];
-#pragma unroll
-                for (int r = 1; r < 5; ++r) acc = cadd(acc, slab[r * 72 + bin]);
-                cf h = cmul(acc, p.inv_training[bin]);                   // 64-entry table, L2/L1 resident
-                h = make_float2(h.x * 0.2f, h.y * 0.2f);
-                if (p.hk) p.hk[f * 64 + bin] = h;
-                const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
-                slab[6 * 72 + bin] = make_float2(h.x * rn, -h.y * rn);   // 1 / H; row 6 is nobody's input
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-                for (int m = 0; m < 8; ++m) g[m] = slab[6 * 72 + t + 8 * m];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                continue;
-            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], g[m]); // equalise (receiver.rs:68-70)
             if (GUARD) {
@@ -331,7 +345,7 @@ template <int BPS> static hipError_t launch_rxframe(const RxFrame64Params &p, bo
 
 // Fused channel estimate + demod for N = 64 frames.  hipErrorNotSupported => caller uses run_chest + run_demod.
 hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, int num_cu, unsigned char *final_out,
-                         long long final_stride, int32_t *final_len) {
+                         long long final_stride, int32_t *final_len, const int32_t *frame_list, const int32_t *frame_count) {
     const int nd = sp.guard ? 48 : 64;
     if ((nd * sp.bps / 8) % 4 != 0 || !sp.nsym_frame || sp.soft) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
@@ -344,7 +358,8 @@ hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, in
     if (final_out && final_len && (reinterpret_cast<uintptr_t>(final_out) & 3) == 0 && (final_stride & 3) == 0) {
         p.final_out = final_out; p.final_stride = final_stride; p.final_len = final_len;
     } else if (final_out) return hipErrorNotSupported;
-    long long blocks = (sp.n_frames + 3) / 4, cap = (long long)num_cu * 8;
+    p.frame_list = frame_list; p.frame_count = frame_count;
+    long long blocks = (sp.n_frames + 3) / 4, cap = frame_list ? 64 : (long long)num_cu * 8;
     const dim3 grid((unsigned)(blocks < cap ? blocks : cap));
     switch (sp.bps) {
     case 2: return launch_rxframe<2>(p, sp.guard != 0, grid, st);

@@ -74,6 +74,7 @@ struct ofdm_ctx {
     float2 *d_tw = nullptr;       // exp(-2 pi i m / N)
     float2 *d_inv_trn = nullptr;  // 1 / training[k]
     float2 *d_header = nullptr;   // 10 * S un-normalised header samples
+    double *d_atan_tab = nullptr; // 32 x (cos, sin)(k pi / 16): the fused receive kernel's f64 atan2 (kernels_sync.hip)
     float header_max = 0.f;
     // workspaces (grown on demand, never inside a captured region)
     Workspace ws[8];
@@ -281,6 +282,7 @@ int ofdm_destroy(ofdm_ctx *c) {
     if (c->d_tw) hipFree(c->d_tw);
     if (c->d_inv_trn) hipFree(c->d_inv_trn);
     if (c->d_header) hipFree(c->d_header);
+    if (c->d_atan_tab) hipFree(c->d_atan_tab);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -357,8 +359,12 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
         for (auto &v : hdr) { hmax = std::fmax(hmax, v.x); hmax = std::fmax(hmax, v.y); }
         c->header_max = hmax;
 
+        double atab[64];
+        for (int k = 0; k < 32; k++) { atab[2 * k] = std::cos(kPi * k / 16.0); atab[2 * k + 1] = std::sin(kPi * k / 16.0); }
         if (hipMalloc(&c->d_tw, sizeof(float2) * N) != hipSuccess || hipMalloc(&c->d_inv_trn, sizeof(float2) * N) != hipSuccess ||
-            hipMalloc(&c->d_header, sizeof(float2) * 10 * S) != hipSuccess) { rc = OFDM_ERR_NOMEM; break; }
+            hipMalloc(&c->d_header, sizeof(float2) * 10 * S) != hipSuccess ||
+            hipMalloc(&c->d_atan_tab, sizeof(atab)) != hipSuccess) { rc = OFDM_ERR_NOMEM; break; }
+        if (hipMemcpy(c->d_atan_tab, atab, sizeof(atab), hipMemcpyHostToDevice) != hipSuccess) { rc = OFDM_ERR_HIP; break; }
         if (hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(c->d_inv_trn, inv.data(), sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(c->d_header, hdr.data(), sizeof(float2) * 10 * S, hipMemcpyHostToDevice) != hipSuccess) { rc = OFDM_ERR_HIP; break; }
@@ -529,23 +535,31 @@ int ofdm_hamming74_decode(ofdm_ctx *c, const uint8_t *in, int64_t n_bytes, uint8
     return OFDM_OK;
 }
 
-static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
-                  int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric) {
+// Schmidl-Cox parameters of a batch; false when no lag fits the capture (nothing can synchronise)
+static bool sc_make_params(const ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                           int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric, ScParams &p) {
     const int L = c->S(), W = c->prm.sync_window_reps * L;
     const int64_t valid = frame_len - W - L + 1;
-    if (valid <= 0) { // no lag fits: nothing can synchronise
+    if (valid <= 0) return false;
+    if (n_lags <= 0 || n_lags > valid) n_lags = valid;
+    p.in = in; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len; p.n_lags = n_lags;
+    p.L = L; p.W = W; p.threshold = (double)c->prm.sync_threshold;
+    p.d_hat = d_hat; p.f_delta = f_delta; p.metric = metric;
+    p.tiles_per_frame = 1; p.mode = 0;
+    return true;
+}
+
+static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                  int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric) {
+    ScParams p;
+    if (!sc_make_params(c, in, n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric, p)) { // no lag fits
         HIP_TRY(c, hipMemsetAsync(d_hat, 0xFF, sizeof(int32_t) * (size_t)n_frames, c->stream));
         if (f_delta) HIP_TRY(c, hipMemsetAsync(f_delta, 0, sizeof(double) * (size_t)n_frames, c->stream));
         if (metric) HIP_TRY(c, hipMemsetAsync(metric, 0, sizeof(float) * (size_t)n_frames, c->stream));
         return OFDM_OK;
     }
-    if (n_lags <= 0 || n_lags > valid) n_lags = valid;
-    ScParams p;
-    p.in = in; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len; p.n_lags = n_lags;
-    p.L = L; p.W = W; p.threshold = (double)c->prm.sync_threshold;
-    p.d_hat = d_hat; p.f_delta = f_delta; p.metric = metric;
+    n_lags = p.n_lags;
     // one-tile frames with a short period: coarse-then-fine f32 filter + exact f64 decisions (k_sc_cf)
-    p.tiles_per_frame = 1; p.mode = 0;
     if (sc_fast_ok(p)) {
         void *wsp;
         int rc = ws_get(c, 6, sc_fast_workspace_bytes(n_frames, p.W), &wsp);
@@ -706,17 +720,53 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     if (!n_frames) return OFDM_OK;
     DeviceGuard dev_guard(c->device);
     const int N = c->prm.n_fft;
-    void *w_dhat, *w_fd, *w_off, *w_nsym, *w_hk, *w_raw;
+    void *w_dhat, *w_fd, *w_off, *w_nsym, *w_hk = nullptr, *w_raw = nullptr;
     int rc;
     if ((rc = ws_get(c, 0, sizeof(int32_t) * (size_t)n_frames, &w_dhat))) return rc;
     if ((rc = ws_get(c, 1, sizeof(double) * (size_t)n_frames, &w_fd))) return rc;
     if ((rc = ws_get(c, 2, sizeof(int32_t) * (size_t)n_frames, &w_off))) return rc;
     if ((rc = ws_get(c, 3, sizeof(int32_t) * (size_t)n_frames, &w_nsym))) return rc;
-    if ((rc = ws_get(c, 4, sizeof(float2) * (size_t)N * (size_t)n_frames, &w_hk))) return rc;
-    if ((rc = ws_get(c, 5, (size_t)raw_stride * (size_t)n_frames, &w_raw))) return rc;
     int32_t *offs = offset ? offset : (int32_t *)w_off;
     double *fd = f_delta ? f_delta : (double *)w_fd;
     const float2 *x = reinterpret_cast<const float2 *>(in);
+    // 0. N = 64 frames that fit one LDS tile: timing, CFO, channel estimate, demod and the finish in ONE kernel and one
+    //    pass over HBM (k_sc_cf<..., BPS>, kernels_sync.hip).  The few frames its f32 filter cannot settle come back on
+    //    a device-side list and take the list-mode kernels below.
+    if (N == 64) {
+        // Opt-in (OFDM_ONE_PASS_RX=1, read per call: the parity tests flip it): measured on MI355X the one-pass kernel moves
+        // half the HBM bytes of the staged chain but is VALU-issue bound with 12 wavefronts per CU (its LDS footprint), 2.2 ms
+        // against 1.95 ms per 262 144 config-3 frames; see DESIGN.md section 5.2.
+        const bool off = getenv("OFDM_ONE_PASS_RX") == nullptr;
+        ScParams scp;
+        ScRxFused rx;
+        rx.bps = c->prm.modulation; rx.guard = c->prm.guard_bands; rx.backoff = c->prm.sync_backoff; rx.cfo_mode = c->prm.cfo_mode;
+        rx.max_symbols = max_symbols; rx.ecc = c->prm.ecc; rx.tw = c->d_tw; rx.inv_training = c->d_inv_trn; rx.atan_tab = c->d_atan_tab;
+        rx.out = out; rx.out_stride = out_stride; rx.out_len = out_len; rx.status = status; rx.offset = offs; rx.f_delta = fd;
+        rx.metric = metric;
+        if (!off && sc_make_params(c, x, n_frames, frame_stride, frame_len, n_lags, (int32_t *)w_dhat, fd, metric, scp) &&
+            sc_rx_fused_ok(scp, rx)) {
+            void *wsp;
+            if ((rc = ws_get(c, 6, sc_fast_workspace_bytes(n_frames, scp.W), &wsp))) return rc;
+            if (c->prm.ecc != OFDM_ECC_NONE && (rc = ws_get(c, 5, (size_t)raw_stride * (size_t)n_frames, &w_raw))) return rc;
+            const int32_t *slow_list = nullptr, *slow_count = nullptr;
+            HIP_TRY(c, run_sc_fast(scp, wsp, c->num_cu, c->stream, &rx, &slow_list, &slow_count));
+            // slow-list frames (k_sc_tile has just redone their timing in f64): prepare -> receive body -> finish
+            HIP_TRY(c, run_rx_prepare(n_frames, (const int32_t *)w_dhat, fd, frame_len, c->S(), c->prm.sync_backoff, c->prm.cfo_mode,
+                                      max_symbols, bps_bytes, status, offs, (int32_t *)w_nsym, c->stream, slow_list, slow_count));
+            SymParams p = base_params(c);
+            p.in = x; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
+            p.offset = offs; p.f_delta = fd; p.nsym_frame = (const int32_t *)w_nsym;
+            const bool fin = c->prm.ecc == OFDM_ECC_NONE;
+            p.out_bytes = fin ? out : (uint8_t *)w_raw; p.out_stride = fin ? out_stride : raw_stride;
+            HIP_TRY(c, fin ? run_rxframe64(p, nullptr, c->stream, c->num_cu, out, out_stride, out_len, slow_list, slow_count)
+                           : run_rxframe64(p, nullptr, c->stream, c->num_cu, nullptr, 0, nullptr, slow_list, slow_count));
+            if (!fin)
+                HIP_TRY(c, run_rx_finish((const uint8_t *)w_raw, raw_stride, n_frames, status, (const int32_t *)w_nsym, bps_bytes,
+                                         c->prm.ecc, out, out_stride, out_len, c->stream, slow_list, slow_count));
+            return OFDM_OK;
+        }
+    }
+    if ((rc = ws_get(c, 5, (size_t)raw_stride * (size_t)n_frames, &w_raw))) return rc;
     // 1. timing + CFO: Schmidl-Cox over the repeated preamble (replaces xcorr_fft, src/receiver.rs:20-25,39)
     rc = sc_run(c, x, n_frames, frame_stride, frame_len, n_lags, (int32_t *)w_dhat, fd, metric);
     if (rc) return rc;
@@ -749,6 +799,7 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         else if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
     if (!fused) {
+        if ((rc = ws_get(c, 4, sizeof(float2) * (size_t)N * (size_t)n_frames, &w_hk))) return rc;
         SymParams p = base_params(c);
         p.in = x; p.out = (float2 *)w_hk; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
         p.offset = offs; p.f_delta = fd;

@@ -815,7 +815,8 @@ orc_rx_info orc_decode_sc(const oc64 *samples, size_t n, int n_fft, int cp, int 
     if (d < 0) { info.status = -2; return info; }
     long offset = (long)d - (long)S - (long)backoff;
     if (offset < 0) offset = 0;
-    if (cfo_abs) fd = fabs(fd);
+    if (cfo_abs == 1) fd = fabs(fd);   /* OFDM_CFO_ABS: the reference's abs() (receiver.rs:239) */
+    else if (cfo_abs == 2) fd = 0.0;   /* OFDM_CFO_OFF: no derotation */
     info = rx_chain(samples, n, offset, fd, n_fft, cp, guard, modulation, training, max_symbols, out, out_cap, soft,
                     soft_cap);
     info.metric = metric;

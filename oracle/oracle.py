@@ -406,13 +406,13 @@ def decode_ref(samples, guard=False, modulation=BPSK, n_fft=64, training=None, w
 
 
 def decode_sc(samples, guard=False, modulation=BPSK, n_fft=64, training=None, window_reps=3, sync_lags=0,
-              threshold=0.5, backoff=4, cfo_abs=False, max_symbols=0, want_soft=False):
+              threshold=0.5, backoff=4, cfo_abs=False, max_symbols=0, want_soft=False, cfo_off=False):
     s = cx(samples)
     trn = default_training(n_fft) if training is None else cx(training)
     out, soft = _rx_buffers(s.size, n_fft, modulation, want_soft)
     info = lib().orc_decode_sc(_c(s), C.c_size_t(s.size), C.c_int(n_fft), C.c_int(n_fft // 4), C.c_int(int(guard)),
                                C.c_int(modulation), _c(trn), C.c_int(window_reps), C.c_long(sync_lags),
-                               C.c_double(threshold), C.c_int(backoff), C.c_int(int(cfo_abs)), C.c_int(max_symbols), _u8(out),
+                               C.c_double(threshold), C.c_int(backoff), C.c_int(2 if cfo_off else int(cfo_abs)), C.c_int(max_symbols), _u8(out),
                                C.c_size_t(out.size), _c(soft), C.c_size_t(0 if soft is None else soft.size))
     return _rx_result(info, out, soft, n_fft, guard)
 

@@ -564,6 +564,72 @@ def test_rx_decode_truncated_and_limited(api, orc, n, mod, guard):
                 assert bytes(res["bytes"][f][: res["len"][f]]) == w["bytes"], (f, max_sym)
 
 
+@pytest.mark.parametrize("mod,guard,ecc,cfo_mode", [(6, True, 0, 1), (6, True, 1, 1), (2, False, 0, 2), (4, True, 0, 0),
+                                                     (8, False, 1, 1), (1, False, 0, 1), (8, True, 0, 2)])
+def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod, guard, ecc, cfo_mode):
+    """The one-pass receive kernel (k_sc_cf<..., BPS>: timing + CFO + channel estimate + demod + finish from the frame's
+    LDS image) against (a) the staged chain (k_sc_cf + k_sc_post + k_rx_prepare + k_rxframe64 [+ k_rx_finish]; switched in
+    the default; the one-pass kernel is switched in with OFDM_ONE_PASS_RX=1) -- every output identical except the CFO (two f64 atan2 evaluations: <= 1e-13) and decisions
+    the CFO's last bits can move -- and (b) the oracle, on a batch that mixes clean frames, noise-only slots (NOSYNC),
+    captures cut inside the header (SHORT) or inside a data symbol (pad_chunk), and a limited symbol count.
+    src/receiver.rs:9-96."""
+    import os
+    rng = np.random.default_rng(900 + mod + ecc + cfo_mode)
+    ctx = api.Context(n_fft=64, modulation=mod, guard_bands=guard, ecc=ecc, cfo_mode=cfo_mode)
+    nbytes = 200 if mod > 1 else 100
+    D = ctx.data_symbols(nbytes)
+    flen = ctx.frame_samples(nbytes)
+    span = (flen + 120) // 2 * 2
+    assert span <= 2560
+    caps, kinds = [], []
+    for f in range(48):
+        pay = bytes(rng.integers(0, 256, nbytes, dtype=np.uint8))
+        body = orc.hamming74_encode(pay) if ecc else pay
+        tx = orc.encode(body, guard, mod, 64)
+        kind = ("ok", "ok", "ok", "noise", "cut_data", "cut_head")[f % 6]
+        fd = (rng.random() * 1.9 - 0.95) * np.pi / 80 * (0.5 if cfo_mode == 2 else 1.0)
+        if cfo_mode == 2:
+            fd = abs(fd)
+        c = through_channel(orc, rng, tx, span, int(rng.integers(1, 100)), fd, 30.0, data_start=800)
+        if kind == "noise":
+            c = fc32(0.05 * (rng.standard_normal(span) + 1j * rng.standard_normal(span)))
+        caps.append(c); kinds.append(kind)
+    caps = np.stack(caps)
+    frame_lens = {"full": span, "cut_data": flen - 100, "cut_head": 700}
+    for label, flen_used in frame_lens.items():
+        for max_sym in (D, max(1, D - 3)):
+            os.environ["OFDM_ONE_PASS_RX"] = "1"
+            try:
+                one = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=max_sym, frame_len=flen_used).items()}
+            finally:
+                os.environ.pop("OFDM_ONE_PASS_RX", None)
+            two = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=max_sym, frame_len=flen_used).items()}
+            assert np.array_equal(one["status"], two["status"]) and np.array_equal(one["offset"], two["offset"])
+            assert np.array_equal(one["len"], two["len"])
+            assert np.allclose(one["f_delta"], two["f_delta"], rtol=0, atol=1e-13)
+            assert np.allclose(one["metric"], two["metric"], rtol=1e-6, atol=0)
+            for f in range(caps.shape[0]):
+                x = wide(caps[f][:flen_used])
+                w = orc.decode_sc(x, guard, mod, 64, window_reps=3, sync_lags=0, threshold=0.5, backoff=4,
+                                  cfo_abs=cfo_mode == 2, cfo_off=cfo_mode == 0, max_symbols=max_sym, want_soft=True)
+                assert one["status"][f] == w["status"], (label, max_sym, f, kinds[f])
+                if w["status"] != 0:
+                    assert one["len"][f] == 0
+                    continue
+                assert one["offset"][f] == w["offset"] and abs(one["f_delta"][f] - w["f_delta"]) <= 1e-12
+                got = bytes(one["bytes"][f][: one["len"][f]])
+                want = orc.hamming74_decode(w["bytes"])[0] if ecc else w["bytes"]
+                if got != want:   # only a decision the oracle itself has within TOL of a boundary may differ
+                    assert not ecc and len(got) == len(want), (label, max_sym, f)
+                    gb = np.unpackbits(np.frombuffer(got, np.uint8), bitorder="little")
+                    wb = np.unpackbits(np.frombuffer(want, np.uint8), bitorder="little")
+                    pts = np.unique((128 + np.nonzero(gb != wb)[0]) // mod)
+                    from util import decision_margin
+                    assert np.all(decision_margin(np.asarray(w["soft"])[pts], mod) < TOL), (label, max_sym, f)
+        if label == "full":
+            assert int((one["status"] == 0).sum()) >= 36 and int((one["status"] == -2).sum()) >= 6
+
+
 def test_decode_errors(api, orc):
     # "Input not long enough, bailing early" (receiver.rs:27-29) and no-sync
     rng = np.random.default_rng(4)
