@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
     kk %= p.groups_per_frame;
     long long g_idx = (long long)blockIdx.x * 4 + wave;
 
+    // (A register prefetch of the next group's samples was measured in round 2: +22 VGPRs, 4 instead of 5 waves per SIMD,
+    // no change in time -- the kernel already sits at the practical DRAM rate)
     for (; g_idx < p.n_groups; g_idx += p.stride_groups) {
         const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + kk * 8) * S + CP + lane_off;
         cf v[8];
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
     constexpr int REGION_DW = ND * BPS / 4;   // 8 symbols
     constexpr int SLAB = 8 * 72;
     __shared__ cf slab_all[4 * SLAB];
+    __shared__ cf ginv_all[4 * 64];           // 1 / H per wavefront, read at use (16 fewer live registers than a register copy)
     __shared__ unsigned img_all[4 * REGION_DW];
 
     const int lane = threadIdx.x & 63;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
         // = FFT(mean_b block_b) / training.  Lane n sums sample n of the 5 derotated blocks, the wavefront transforms the 64
         // sums with one point per lane (lane_fft64), lane l then holds bin bitrev6(l): ONE transform per frame instead of a
         // whole 8-symbol group iteration.  1/H goes through the wave's LDS slab into the (t + 8 m) register layout.
-        cf g[8];
+        cf *ginv = ginv_all + wave * 64;
         {
             cf tws[6];
 #pragma unroll
@@ -247,12 +250,8 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
             h = make_float2(h.x * 0.2f, h.y * 0.2f);
             if (p.hk) p.hk[f * 64 + bin] = h;
             const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
-            cf *slab = slab_all + wave * SLAB;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            slab[bin] = make_float2(h.x * rn, -h.y * rn);            // 1 / H
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-            for (int m = 0; m < 8; ++m) g[m] = slab[t + 8 * m];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // the previous frame's last reads of this table are done
+            ginv[bin] = make_float2(h.x * rn, -h.y * rn);            // 1 / H
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         for (int k0 = 0; k0 < ns; k0 += 8) { // data symbols, 8 at a time (chunks 10..)
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             bfly8<false>(v);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], g[m]); // equalise (receiver.rs:68-70)
+            for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], ginv[t + 8 * m]); // equalise (receiver.rs:68-70)
             if (GUARD) {
                 cf pv = make_float2(1.f, 0.f);
                 pv = (t == 6) ? v[0] : pv;
@@ -1118,13 +1117,42 @@ hipError_t run_tx4096(const SymParams &sp, hipStream_t st, int num_cu) {
     return hipGetLastError();
 }
 
-template <int BPS> static hipError_t launch_bps(const Fast64Params &p, bool guard, dim3 grid, hipStream_t st) {
-    const bool hk = p.hk != nullptr;
-    if (guard && hk) hipLaunchKernelGGL((k_demod64<BPS, true, true>), grid, dim3(256), 0, st, p);
-    else if (guard) hipLaunchKernelGGL((k_demod64<BPS, true, false>), grid, dim3(256), 0, st, p);
-    else if (hk) hipLaunchKernelGGL((k_demod64<BPS, false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_demod64<BPS, false, false>), grid, dim3(256), 0, st, p);
+// Persistent grid: resident workgroups per CU from the occupancy API (per instantiation and device, cached), doubled up
+// to the 8 the round-1 launcher used -- measured (OFDM_DEMOD64_WG_PER_CU sweep, 1 M frames): 3 -> 1.77 ms, 4 -> 1.70,
+// 5 -> 1.81, 8 -> 1.68: a second, queued round of workgroups evens out the tail.
+template <typename K> static int resident_blocks(K kernel, int block) {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 4;
+        cached[dev] = n > 8 ? 8 : n;
+    }
+    return cached[dev];
+}
+template <int BPS, bool GUARD, bool HK> static hipError_t launch_demod64(Fast64Params p, hipStream_t st, int num_cu) {
+    auto kernel = k_demod64<BPS, GUARD, HK>;
+    long long waves = (p.n_groups + 3) / 4 * 4;
+    static const int knob = [] { const char *v = getenv("OFDM_DEMOD64_WG_PER_CU"); return v ? atoi(v) : 0; }(); // tuning knob
+    const long long cap = (long long)num_cu * (knob > 0 ? knob : (resident_blocks(kernel, 256) >= 4 ? 8 : 2 * resident_blocks(kernel, 256))) * 4;
+    if (waves > cap) waves = cap;
+    const int grid = (int)(waves / 4);
+    p.stride_groups = (long long)grid * 4;
+    const int gpf = p.groups_per_frame;
+    p.f0 = 0; p.k0 = 0;
+    p.blk_df = 4 / gpf; p.blk_dk = 4 % gpf;    // a block advances the group index by 4
+    p.wave_df = 0; p.wave_dk = 1;              // a wave by 1 (normalised in the kernel)
+    p.step_df = p.stride_groups / gpf; p.step_dk = (int)(p.stride_groups % gpf);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();
+}
+template <int BPS> static hipError_t launch_bps(const Fast64Params &p, bool guard, hipStream_t st, int num_cu) {
+    const bool hk = p.hk != nullptr;
+    if (guard && hk) return launch_demod64<BPS, true, true>(p, st, num_cu);
+    if (guard) return launch_demod64<BPS, true, false>(p, st, num_cu);
+    if (hk) return launch_demod64<BPS, false, true>(p, st, num_cu);
+    return launch_demod64<BPS, false, false>(p, st, num_cu);
 }
 
 // Returns hipErrorNotSupported when the request is outside the fast path's envelope (caller falls back to k_sym).
@@ -1141,22 +1169,12 @@ hipError_t run_demod64_fast(const SymParams &sp, hipStream_t st, int num_cu) {
     p.groups_per_frame = sp.syms_per_frame / 8;
     p.n_groups = sp.n_frames * (long long)p.groups_per_frame;
     if (p.n_groups <= 0) return hipSuccess;
-    long long waves = (p.n_groups + 3) / 4 * 4;
-    long long cap = (long long)num_cu * 8 * 4; // 8 workgroups per CU
-    if (waves > cap) waves = cap;
-    const int grid = (int)(waves / 4);
-    p.stride_groups = (long long)grid * 4;
-    const int gpf = p.groups_per_frame;
-    p.f0 = 0; p.k0 = 0;
-    p.blk_df = 4 / gpf; p.blk_dk = 4 % gpf;    // a block advances the group index by 4
-    p.wave_df = 0; p.wave_dk = 1;              // a wave by 1 (normalised in the kernel)
-    p.step_df = p.stride_groups / gpf; p.step_dk = (int)(p.stride_groups % gpf);
     switch (sp.bps) {
-    case 1: return launch_bps<1>(p, sp.guard != 0, dim3(grid), st);
-    case 2: return launch_bps<2>(p, sp.guard != 0, dim3(grid), st);
-    case 4: return launch_bps<4>(p, sp.guard != 0, dim3(grid), st);
-    case 6: return launch_bps<6>(p, sp.guard != 0, dim3(grid), st);
-    case 8: return launch_bps<8>(p, sp.guard != 0, dim3(grid), st);
+    case 1: return launch_bps<1>(p, sp.guard != 0, st, num_cu);
+    case 2: return launch_bps<2>(p, sp.guard != 0, st, num_cu);
+    case 4: return launch_bps<4>(p, sp.guard != 0, st, num_cu);
+    case 6: return launch_bps<6>(p, sp.guard != 0, st, num_cu);
+    case 8: return launch_bps<8>(p, sp.guard != 0, st, num_cu);
     default: return hipErrorNotSupported;
     }
 }
