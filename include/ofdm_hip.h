@@ -219,6 +219,11 @@ int ofdm_rx_decode_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frame
 
 /* ------------------------------------------------------------------ measurement helpers
  * HIP events on the context's stream, so a host without HIP bindings can time kernels (bench.py). */
+/* Read-only stream over n_symbols 80-sample (640-byte) symbols at in_dev, nothing but the loads: the practical HBM read
+ * ceiling of an access pattern, to read the demod kernel's rate against.  pattern 0 = the N = 64 demod kernel's access
+ * (8-byte loads, the 128-byte cyclic prefix of every symbol never touched), 1 = the same loads over whole symbols,
+ * 2 = unit-stride 16-byte loads.  Enqueued on the context's stream; time it with ofdm_timer_start / _stop_ms. */
+int ofdm_hbm_read_probe(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_symbols, int32_t pattern);
 int ofdm_timer_start(ofdm_ctx *ctx);
 int ofdm_timer_stop_ms(ofdm_ctx *ctx, float *elapsed_ms); /* records, synchronises, returns elapsed */
 

@@ -373,6 +373,12 @@ class Context:
                                                _dev(res["metric"])), "rx_decode")
         return res
 
+    def hbm_read_probe(self, samples: torch.Tensor, pattern: int = 0):
+        """Measurement helper: read-only pass over a buffer of 80-sample symbols in the demod kernel's access pattern (0),
+        over whole symbols (1) or with unit-stride 16-byte loads (2)."""
+        samples = self._cx(samples)
+        self._ck(self.lib.ofdm_hbm_read_probe(self.h, _dev(samples), samples.numel() // 80, pattern), "hbm_read_probe")
+
     # event timing on the context's stream (bench.py)
     def timer_start(self):
         self._ck(self.lib.ofdm_timer_start(self.h), "timer_start")

@@ -148,4 +148,8 @@ hipError_t run_rx_finish(const uint8_t *raw, long long raw_stride, long long n_f
                          int32_t *out_len, hipStream_t st, const int32_t *frame_list = nullptr,
                          const int32_t *frame_count = nullptr);
 
+// measurement helper (ofdm_hbm_read_probe): read-only stream in k_demod64's access pattern (0), over whole symbols (1), or
+// with unit-stride 16-byte loads (2)
+hipError_t run_read_probe(const float2 *in, long long n_sym, int pattern, unsigned *sink, int num_cu, hipStream_t st);
+
 } // namespace ofdm

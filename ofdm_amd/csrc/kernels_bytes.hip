@@ -286,4 +286,43 @@ hipError_t run_rx_finish(const uint8_t *raw, long long raw_stride, long long n_f
     return hipGetLastError();
 }
 
+// ---- measurement helper: read-only stream over a config-2 shaped buffer, nothing but the loads (ofdm_hbm_read_probe).
+// pattern 0: k_demod64's access -- 8-byte loads, the 128-byte cyclic prefix of every 640-byte symbol never touched;
+// pattern 1: the same 8-byte loads over ALL 640 bytes of every symbol; pattern 2: unit-stride 16-byte loads.
+// The practical ceiling of each pattern is what the demod kernel's rate should be read against.
+__global__ __launch_bounds__(256) void k_read_probe(const float2 *in, long long n_sym, int pattern, unsigned *sink) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+    float acc = 0.f;
+    if (pattern == 2) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(in);
+        const long long n4 = n_sym * 40; // 640 B / 16
+        for (long long i = wave * 64 + lane; i < n4; i += n_waves * 64 * 4) {
+            float4 a = p4[i], b = make_float4(0, 0, 0, 0), c = b, d = b;
+            if (i + n_waves * 64 < n4) b = p4[i + n_waves * 64];
+            if (i + 2 * n_waves * 64 < n4) c = p4[i + 2 * n_waves * 64];
+            if (i + 3 * n_waves * 64 < n4) d = p4[i + 3 * n_waves * 64];
+            acc += a.x + a.w + b.x + b.w + c.x + c.w + d.x + d.w;
+        }
+    } else {
+        const int s = lane >> 3, t = lane & 7;
+        for (long long g = wave; g * 8 < n_sym; g += n_waves) { // 8 symbols per wavefront and step, as k_demod64
+            const float2 *src = in + (g * 8 + s) * 80 + t;
+            if (pattern == 0) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { const float2 v = src[16 + 8 * m]; acc += v.x + v.y; }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 10; ++m) { const float2 v = src[8 * m]; acc += v.x + v.y; }
+            }
+        }
+    }
+    if (acc == 12345.678f) sink[0] = 1u; // keeps the loads alive
+}
+hipError_t run_read_probe(const float2 *in, long long n_sym, int pattern, unsigned *sink, int num_cu, hipStream_t st) {
+    if (n_sym <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_read_probe, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, in, n_sym, pattern, sink);
+    return hipGetLastError();
+}
+
 } // namespace ofdm

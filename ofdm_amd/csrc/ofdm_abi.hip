@@ -815,6 +815,16 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     return OFDM_OK;
 }
 
+int ofdm_hbm_read_probe(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_symbols, int32_t pattern) {
+    if (!c || n_symbols < 0 || pattern < 0 || pattern > 2 || (n_symbols && !in)) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
+    void *sink;
+    int rc = ws_get(c, 7, 64, &sink);
+    if (rc) return rc;
+    HIP_TRY(c, run_read_probe(reinterpret_cast<const float2 *>(in), n_symbols, pattern, (unsigned *)sink, c->num_cu, c->stream));
+    return OFDM_OK;
+}
+
 int ofdm_timer_start(ofdm_ctx *c) {
     if (!c) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
