@@ -30,8 +30,12 @@ def parse():
     ap.add_argument("--snr-db", type=float, default=30.0)
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-cfg3", action="store_true", help="skip the config-3 (full RX chain / Schmidl-Cox) report")
-    ap.add_argument("--cfg3-frames", type=int, default=262_144)
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the config 3 / 4 / 5 reports (headline only)")
+    ap.add_argument("--cfg3-frames", type=int, default=1_000_000, help="BASELINE config 3: 1M frames")
+    ap.add_argument("--cfg4-ring", type=int, default=65536, help="config 4: frames in the resident ring")
+    ap.add_argument("--cfg4-frames", type=int, default=10_000_000, help="config 4: frames counted (BASELINE: 10M-frame stream)")
+    ap.add_argument("--cfg5-symbols", type=int, default=65536)
+    ap.add_argument("--cpu-seconds", type=float, default=2.5, help="wall time of each CPU-baseline leg")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only: no GPU work, value null (CPU tests)")
     return ap.parse_args()
@@ -113,24 +117,41 @@ def synth_cfg2(ctx, torch, n_frames, syms, snr_db, seed):
     return x, payload
 
 
-def cpu_baseline_cfg2(x_host, syms, n_threads):
-    """The oracle (kind "port": the reference cannot be built here) timed on the host cores on a bounded sample."""
+def cpu_baseline_cfg2(x_host, syms, gpu_bytes, target_s):
+    """The oracle (kind "port": the reference cannot be built here) timed on the host cores on a bounded sample, three ways
+    (SURVEY.md 8d): ref-faithful single thread (twiddles regenerated on every transform, as the reference re-plans its FFT on
+    every call, src/signals/mod.rs:41-58), cached-twiddle single thread, cached on all cores.  Returns the cpu_baseline
+    object (value = all cores) and whether the GPU's bytes for the same frames equal the CPU's."""
     import numpy as np
-    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
+    from tools import cpu_baseline as cb
 
     orc.lib()
     F = x_host.shape[0]
-    xs = [np.ascontiguousarray(x_host[i::n_threads].reshape(-1)).astype(np.complex128) for i in range(n_threads)]
+    threads = cb.host_threads()
+    one = [np.ascontiguousarray(x_host[: max(1, F // threads)].reshape(-1)).astype(np.complex128)]
+    blocks = [np.ascontiguousarray(x_host[i::threads].reshape(-1)).astype(np.complex128) for i in range(threads)]
 
     def work(a):
         return orc.rx_demod(a, 64, True, orc.QAM64)
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(n_threads) as ex:  # ctypes releases the GIL inside the C oracle
-        outs = list(ex.map(work, xs))
-    dt = time.perf_counter() - t0
-    return F * syms * 80 / dt / 1e6, dt, outs
+    legs = {}
+    orc.set_fft_cache(False)
+    legs["ref_faithful_1_thread"], _ = cb.timed(work, one, one[0].size / 1e6, target_s)
+    orc.set_fft_cache(True)
+    legs["cached_twiddles_1_thread"], _ = cb.timed(work, one, one[0].size / 1e6, target_s)
+    legs["cached_twiddles_all_cores"], outs = cb.timed(work, blocks, F * syms * 80 / 1e6, target_s)
+    orc.set_fft_cache(False)
+    same = all(bytes(gpu_bytes[i::threads].reshape(-1)) == outs[i] for i in range(threads))
+    top = legs["cached_twiddles_all_cores"]
+    rec = {"value": top["value"], "unit": "Msamples/s", "cores": threads, "kind": "port",
+           "sample": f"first {F} frames of the same batch ({F * syms * 80} samples) x {top['passes_over_sample']} passes, oracle rx_demod "
+                     f"(f64, cached twiddles, {threads} threads), {top['seconds']:.1f} s wall",
+           "host_cpus": os.cpu_count(),
+           "variants": {k: {"value": v["value"], "unit": "Msamples/s", "threads": v["threads"], "wall_s": v["seconds"],
+                            "passes_over_sample": v["passes_over_sample"]} for k, v in legs.items()},
+           "gpu_bytes_equal_cpu_bytes": bool(same)}
+    return rec
 
 
 def dry_run(a):
@@ -261,39 +282,27 @@ def main():
         res["weak_scaling_efficiency_in_run"] = (n_gpus * samples_per_step / (dt / a.steps)) / (n_gpus * samples_per_step / (solo_ms / 1e3))
 
     if rank == 0 and n_gpus == 1 and not a.no_cpu:
-        ncores = os.cpu_count() or 1
-        nthreads = max(1, min(ncores, 64))
-        ncpu = a.cpu_frames or 4000 * nthreads
-        ncpu = min(ncpu, F)
+        ncpu = min(a.cpu_frames or 131072, F)
         xh = x[:ncpu].cpu().numpy()
-        msps, cdt, outs = cpu_baseline_cfg2(xh, syms, nthreads)
-        # the same sample on the GPU must give the same bytes as the CPU path (identical decoded BER)
-        gpu_bytes = out[:ncpu].cpu().numpy()
-        same = all(bytes(gpu_bytes[i::nthreads].reshape(-1)) == outs[i] for i in range(nthreads))
-        res["cpu_baseline"] = {"value": msps, "unit": "Msamples/s", "cores": nthreads, "kind": "port",
-                               "sample": f"first {ncpu} frames of the same batch ({ncpu * syms * 80} samples), "
-                                         f"oracle rx_demod (f64), {cdt:.1f} s wall", "gpu_bytes_equal_cpu_bytes": bool(same)}
-        res["speedup_vs_cpu"] = value / msps if msps > 0 else None
+        res["cpu_baseline"] = cpu_baseline_cfg2(xh, syms, out[:ncpu].cpu().numpy(), a.cpu_seconds)
+        res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"] if res["cpu_baseline"]["value"] > 0 else None
+        del xh
 
+    # BASELINE configs 3, 4, 5 at their stated sizes on this GPU (rank 0 of a single-GPU run): each block carries its own
+    # roofline, bounded-sample CPU baseline and GPU-vs-CPU equality.  The headline line above must survive their failure.
     if rank == 0 and n_gpus == 1 and not a.no_cfg3:
-        try:
-            from tools import bench_cfg3
-
-            del x, payload, out
+        del x, payload, out
+        torch.cuda.empty_cache()
+        for name, fn in (("cfg3", lambda: __import__("tools.bench_cfg3", fromlist=["run"]).run(
+                                     api, torch, a.cfg3_frames, max(3, a.steps // 4), local, cpu=not a.no_cpu)),
+                         ("cfg5", lambda: __import__("tools.bench_large_n", fromlist=["cfg5"]).cfg5(a.cfg5_symbols, 5, cpu=not a.no_cpu)),
+                         ("cfg4", lambda: __import__("tools.bench_large_n", fromlist=["cfg4"]).cfg4(a.cfg4_ring, a.cfg4_frames, cpu=not a.no_cpu))):
+            try:
+                res[name] = fn()
+            except Exception as e:
+                import traceback
+                res[name] = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
             torch.cuda.empty_cache()
-            res["cfg3"] = bench_cfg3.run(api, torch, a.cfg3_frames, max(3, a.steps // 4), local)
-        except Exception as e:  # the headline number must not be lost to the secondary report
-            res["cfg3"] = {"error": repr(e)}
-
-    if rank == 0 and n_gpus == 1 and not a.no_cfg3:
-        try:  # configs 4 and 5 on this GPU (N = 1024 chain, N = 4096 TX + RX): a few seconds, informational
-            from tools import bench_large_n
-
-            torch.cuda.empty_cache()
-            res["cfg5"] = bench_large_n.cfg5(steps=3)
-            res["cfg4"] = bench_large_n.cfg4(steps=3)
-        except Exception as e:
-            res["cfg45_error"] = repr(e)
 
     if rank == 0:
         print(json.dumps(res))

@@ -84,6 +84,8 @@ extern "C" {
     pub fn ofdm_rx_decode_batch(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, n_frames: i64, frame_stride: i64, frame_len: i64,
                                 n_lags: i64, max_symbols: i32, out_dev: *mut u8, out_stride: i64, out_len_dev: *mut i32,
                                 status_dev: *mut i32, offset_dev: *mut i32, f_delta_dev: *mut f64, metric_dev: *mut f32) -> c_int;
+    pub fn ofdm_channel_batch(ctx: *mut ofdm_ctx, tx_dev: *const ofdm_fc32, n_frames: i64, tx_stride: i64, tx_len: i64, snr_db: f64, timing_error: i32, seed: u64, delay_dev: *const i32, f_delta_in_dev: *const f64, out_dev: *mut ofdm_fc32, out_stride: i64, out_len: i64, f_delta_out_dev: *mut f64) -> c_int;
+    pub fn ofdm_channel_taps(taps64: *mut f64) -> c_int;
     pub fn ofdm_hbm_read_probe(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, n_symbols: i64, pattern: i32) -> c_int;
     pub fn ofdm_timer_start(ctx: *mut ofdm_ctx) -> c_int;
     pub fn ofdm_timer_stop_ms(ctx: *mut ofdm_ctx, elapsed_ms: *mut f32) -> c_int;

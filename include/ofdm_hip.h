@@ -217,6 +217,23 @@ int ofdm_rx_decode_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frame
                          int64_t out_stride, int32_t *out_len_dev, int32_t *status_dev, int32_t *offset_dev,
                          double *f_delta_dev, float *metric_dev);
 
+/* ------------------------------------------------------------------ loop-back test bench
+ * channel (src/channel.rs:33-74), per frame:
+ *     y = convolve(tx, CHANNEL)                          tx_len + 63 samples (CHANNEL: the 64 taps of channel.rs:26-31)
+ *     timing_error:  y[i] *= exp(+j f (i + 1)),  f = pi U(0,1) / 80                                   (channel.rs:48-62)
+ *     y[i] += sqrt(0.5 var / snr) (U(-1,1) + j U(-1,1)),  var = the complex pseudo-variance of y, snr = 10^(snr_db/10)
+ * The reference draws from an unseeded thread_rng; here frame f draws from SplitMix64(seed + f) in the reference's order
+ * (f first when timing_error, then re, im per sample) -- the stream oracle/ofdm_oracle.c:orc_channel uses, so the two can be
+ * compared sample by sample.  Test-bench extensions, NULL = the reference's behaviour: delay_dev[f] >= 0 places the channel
+ * output at out + delay[f] (what does not fit out_len is dropped; every one of the out_len slot samples receives noise, the
+ * samples outside the channel output nothing else), f_delta_in_dev[f] replaces the drawn CFO (any sign).
+ * out_len >= tx_len + 63, out_stride >= out_len.  f_delta_out_dev (optional): the CFO applied to each frame. */
+int ofdm_channel_batch(ofdm_ctx *ctx, const ofdm_fc32 *tx_dev, int64_t n_frames, int64_t tx_stride, int64_t tx_len,
+                       double snr_db, int32_t timing_error, uint64_t seed, const int32_t *delay_dev,
+                       const double *f_delta_in_dev, ofdm_fc32 *out_dev, int64_t out_stride, int64_t out_len,
+                       double *f_delta_out_dev);
+int ofdm_channel_taps(double *taps64); /* CHANNEL (src/channel.rs:26-31). Host call. */
+
 /* ------------------------------------------------------------------ measurement helpers
  * HIP events on the context's stream, so a host without HIP bindings can time kernels (bench.py). */
 /* Read-only stream over n_symbols 80-sample (640-byte) symbols at in_dev, nothing but the loads: the practical HBM read

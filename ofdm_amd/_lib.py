@@ -67,6 +67,8 @@ SIGNATURES = {
     "ofdm_rx_demod_batch": (C.c_int, [vp, vp, i64, i64, i64, i32, i32, vp, vp, vp, i64, vp, i64, vp]),
     "ofdm_tx_encode_batch": (C.c_int, [vp, vp, i64, i64, vp, i32, vp, i64]),
     "ofdm_rx_decode_batch": (C.c_int, [vp, vp, i64, i64, i64, i64, i32, vp, i64, vp, vp, vp, vp, vp]),
+    "ofdm_channel_batch": (C.c_int, [vp, vp, i64, i64, i64, C.c_double, i32, C.c_uint64, vp, vp, vp, i64, i64, vp]),
+    "ofdm_channel_taps": (C.c_int, [vp]),
     "ofdm_hbm_read_probe": (C.c_int, [vp, vp, i64, i32]),
     "ofdm_timer_start": (C.c_int, [vp]),
     "ofdm_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),

@@ -373,6 +373,28 @@ class Context:
                                                _dev(res["metric"])), "rx_decode")
         return res
 
+    def channel_batch(self, tx: torch.Tensor, snr_db: float = 30.0, timing_error: bool = False, seed: int = 1,
+                      delay: Optional[torch.Tensor] = None, f_delta: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None, span: Optional[int] = None, want_f_delta: bool = False):
+        """channel (src/channel.rs:33-74) for every row of tx [n_frames, len]: FIR CHANNEL, optional CFO, pseudo-variance
+        noise, seeded (frame f: SplitMix64(seed + f)).  delay (int32) / f_delta (float64) per frame are test-bench
+        extensions; span = samples per output row (default len + 63)."""
+        tx = self._cx(tx)
+        n, ln = tx.shape
+        if out is None:
+            out = self.empty((n, (ln + 63) if span is None else span), torch.complex64)
+        out = self._cx(out)
+        assert out.shape[0] == n
+        fdo = self.empty((n,), torch.float64) if want_f_delta else None
+        if delay is not None:
+            delay = delay.to(device=self.device, dtype=torch.int32).contiguous()
+        if f_delta is not None:
+            f_delta = f_delta.to(device=self.device, dtype=torch.float64).contiguous()
+        self._ck(self.lib.ofdm_channel_batch(self.h, _dev(tx), n, ln, ln, float(snr_db), int(timing_error), int(seed) & (2 ** 64 - 1),
+                                             _dev(delay), _dev(f_delta), _dev(out), out.shape[-1], out.shape[-1], _dev(fdo)),
+                 "channel")
+        return (out, fdo) if want_f_delta else out
+
     def hbm_read_probe(self, samples: torch.Tensor, pattern: int = 0):
         """Measurement helper: read-only pass over a buffer of 80-sample symbols in the demod kernel's access pattern (0),
         over whole symbols (1) or with unit-stride 16-byte loads (2)."""
@@ -410,6 +432,16 @@ def encode(data: bytes, guard_bands: Optional[bool] = None, modulation: Optional
     frames = ctx.encode_batch(pay)
     ctx.synchronize()
     return frames[0].cpu().numpy().astype(np.complex128)
+
+
+def channel(transmission, snr: Optional[float] = None, timing_error: Optional[bool] = None, seed: int = 1) -> np.ndarray:
+    """`ofdm::channel!(transmission, snr, timing_error)` (src/channel.rs:32-74) on the GPU, seeded (the reference's
+    thread_rng is not reproducible).  Defaults as the reference: snr 30 dB, timing_error false."""
+    ctx = _ctx(64, BPSK, False)
+    x = ctx.to_device(np.asarray(transmission)).reshape(1, -1)
+    y = ctx.channel_batch(x, 30.0 if snr is None else snr, bool(timing_error), seed)
+    ctx.synchronize()
+    return y[0].cpu().numpy().astype(np.complex128)
 
 
 def decode(samples, guard_bands: Optional[bool] = None, modulation: Optional[int] = None, n_fft: int = 64,

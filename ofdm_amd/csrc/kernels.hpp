@@ -148,6 +148,24 @@ hipError_t run_rx_finish(const uint8_t *raw, long long raw_stride, long long n_f
                          int32_t *out_len, hipStream_t st, const int32_t *frame_list = nullptr,
                          const int32_t *frame_count = nullptr);
 
+// channel (src/channel.rs:33-74) on the GPU (kernels_bytes.hip)
+struct ChannelParams {
+    const float2 *tx = nullptr;
+    long long n_frames = 0, tx_stride = 0, tx_len = 0;
+    double snr_lin = 1000.0;
+    int timing_error = 0;
+    unsigned long long seed = 0;
+    const int32_t *delay = nullptr;      // optional test-bench extension: per-frame placement inside the slot
+    const double *f_delta_in = nullptr;  // optional test-bench extension: per-frame CFO instead of the drawn one
+    float2 *out = nullptr;
+    long long out_stride = 0, out_len = 0;
+    double *f_delta_out = nullptr;
+    int n_taps = 0;                      // the non-zero taps of CHANNEL
+    int tap_idx[16] = {0};
+    float tap_val[16] = {0};
+};
+hipError_t run_channel(const ChannelParams &p, int num_cu, hipStream_t st);
+
 // measurement helper (ofdm_hbm_read_probe): read-only stream in k_demod64's access pattern (0), over whole symbols (1), or
 // with unit-stride 16-byte loads (2)
 hipError_t run_read_probe(const float2 *in, long long n_sym, int pattern, unsigned *sink, int num_cu, hipStream_t st);

@@ -286,6 +286,95 @@ hipError_t run_rx_finish(const uint8_t *raw, long long raw_stride, long long n_f
     return hipGetLastError();
 }
 
+// ---- channel (src/channel.rs:33-74), the loop-back test bench: FIR CHANNEL, optional CFO, uniform "noise" scaled by the
+// complex pseudo-variance.  One 256-thread workgroup per frame, two sweeps: (1) y = convolve(tx, h) * exp(+j f (i + 1)),
+// written to its place in the slot, with sum(y) and sum(y^2) reduced over the workgroup in f64 (variance = sum((mean - y)^2) / n
+// = sum(y^2) / n - mean^2, signals/mod.rs:239-249: the square is NOT conjugated, so the noise scale is complex);
+// (2) every slot sample gets scale * (U(-1,1) + j U(-1,1)).  Random draws: SplitMix64(seed + frame), counter-indexed so that
+// draw k is the k-th value the sequential oracle (orc_channel) would draw: f_delta first when timing_error, then re, im
+// per sample.
+__device__ __forceinline__ unsigned long long splitmix_at(unsigned long long seed, unsigned long long k) {
+    unsigned long long z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01_at(unsigned long long seed, unsigned long long k) {
+    return (double)(splitmix_at(seed, k) >> 11) * (1.0 / 9007199254740992.0);
+}
+__global__ __launch_bounds__(256) void k_channel(ChannelParams p) {
+    __shared__ double red[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long m = p.tx_len + 63; // convolve: len + 64 - 1 (signals/mod.rs:219-237)
+    for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+        const unsigned long long seed = p.seed + (unsigned long long)f;
+        const float2 *x = p.tx + f * p.tx_stride;
+        float2 *o = p.out + f * p.out_stride;
+        long long delay = p.delay ? p.delay[f] : 0;
+        if (delay < 0) delay = 0;
+        const bool cfo = p.timing_error || p.f_delta_in;
+        double fd = 0.0;
+        if (p.f_delta_in) fd = p.f_delta_in[f];
+        else if (p.timing_error) fd = 3.14159265358979323846 * (u01_at(seed, 0) / 80.0); // channel.rs:54
+        const unsigned long long k0 = cfo ? 1ull : 0ull;
+        const double turns = fd * 0.15915494309189533577;
+        double sr = 0.0, si = 0.0, qr = 0.0, qi = 0.0;
+        for (long long i = tid; i < m; i += 256) {
+            double yr = 0.0, yi = 0.0;
+            for (int t = 0; t < p.n_taps; ++t) {
+                const long long j = i - p.tap_idx[t];
+                if (j >= 0 && j < p.tx_len) { const float2 v = x[j]; yr += (double)p.tap_val[t] * v.x; yi += (double)p.tap_val[t] * v.y; }
+            }
+            if (cfo) { // y[i] *= exp(+j f_delta (i + 1))  (channel.rs:58-62); phase reduced in f64
+                double ph = turns * (double)(i + 1);
+                ph -= rint(ph);
+                double sn, cs;
+                sincospi(2.0 * ph, &sn, &cs);
+                const double a = yr * cs - yi * sn, b = yr * sn + yi * cs;
+                yr = a; yi = b;
+            }
+            if (delay + i < p.out_len) o[delay + i] = make_float2((float)yr, (float)yi);
+            sr += yr; si += yi; qr += yr * yr - yi * yi; qi += 2.0 * yr * yi;
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            sr += __shfl_xor(sr, sft, 64); si += __shfl_xor(si, sft, 64);
+            qr += __shfl_xor(qr, sft, 64); qi += __shfl_xor(qi, sft, 64);
+        }
+        __syncthreads(); // the previous frame's readers of `red` are done; sweep-1 stores are visible to the workgroup
+        if (lane == 0) { red[wave][0] = sr; red[wave][1] = si; red[wave][2] = qr; red[wave][3] = qi; }
+        __syncthreads();
+        sr = red[0][0] + red[1][0] + red[2][0] + red[3][0]; si = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        qr = red[0][2] + red[1][2] + red[2][2] + red[3][2]; qi = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+        const double n = (double)m, mr = sr / n, mi = si / n;
+        const double vr = qr / n - (mr * mr - mi * mi), vi = qi / n - 2.0 * mr * mi; // pseudo-variance
+        const double ar = 0.5 * vr / p.snr_lin, ai = 0.5 * vi / p.snr_lin;          // 0.5 * noise_var (channel.rs:66-69)
+        double cr, ci;                                                             // principal complex square root
+        {
+            const double r = hypot(ar, ai);
+            if (r == 0.0) { cr = 0.0; ci = 0.0; }
+            else if (ar >= 0.0) { const double t = sqrt(0.5 * (r + ar)); cr = t; ci = ai / (2.0 * t); }
+            else { const double t = sqrt(0.5 * (r - ar)); cr = fabs(ai) / (2.0 * t); ci = copysign(t, ai); }
+        }
+        if (tid == 0 && p.f_delta_out) p.f_delta_out[f] = fd;
+        for (long long j = tid; j < p.out_len; j += 256) {
+            const double ur = u01_at(seed, k0 + 2ull * (unsigned long long)j) * 2.0 - 1.0;
+            const double ui = u01_at(seed, k0 + 2ull * (unsigned long long)j + 1ull) * 2.0 - 1.0;
+            const double nr = cr * ur - ci * ui, ni = cr * ui + ci * ur;
+            float2 b = make_float2(0.f, 0.f);
+            if (j >= delay && j < delay + m) b = o[j];
+            o[j] = make_float2(b.x + (float)nr, b.y + (float)ni);
+        }
+    }
+}
+hipError_t run_channel(const ChannelParams &p, int num_cu, hipStream_t st) {
+    if (p.n_frames <= 0) return hipSuccess;
+    long long grid = (long long)num_cu * 8;
+    if (grid > p.n_frames) grid = p.n_frames;
+    hipLaunchKernelGGL(k_channel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 // ---- measurement helper: read-only stream over a config-2 shaped buffer, nothing but the loads (ofdm_hbm_read_probe).
 // pattern 0: k_demod64's access -- 8-byte loads, the 128-byte cyclic prefix of every 640-byte symbol never touched;
 // pattern 1: the same 8-byte loads over ALL 640 bytes of every symbol; pattern 2: unit-stride 16-byte loads.

@@ -815,6 +815,37 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     return OFDM_OK;
 }
 
+// CHANNEL (src/channel.rs:26-31): 64 taps, the non-zero ones are 8..16 and 18
+static const double kChannelTaps[64] = {
+    0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -0.0000, -0.1912, 0.9316, 0.2821, -0.1990, 0.1630, -0.1017, 0.0544, -0.0261,
+    0.0090, 0.0000, -0.0034};
+
+int ofdm_channel_taps(double *taps64) {
+    if (!taps64) return OFDM_ERR_INVALID;
+    for (int i = 0; i < 64; i++) taps64[i] = kChannelTaps[i];
+    return OFDM_OK;
+}
+
+int ofdm_channel_batch(ofdm_ctx *c, const ofdm_fc32 *tx, int64_t n_frames, int64_t tx_stride, int64_t tx_len, double snr_db,
+                       int32_t timing_error, uint64_t seed, const int32_t *delay, const double *f_delta_in, ofdm_fc32 *out,
+                       int64_t out_stride, int64_t out_len, double *f_delta_out) {
+    if (!c || n_frames < 0 || tx_len <= 0 || tx_stride < 0 || out_len < tx_len + 63 || out_stride < out_len) return OFDM_ERR_INVALID;
+    if (n_frames && (!tx || !out)) return OFDM_ERR_INVALID;
+    if (n_frames > 1 && tx_stride <= 0) return OFDM_ERR_INVALID;
+    if (!(snr_db == snr_db)) return OFDM_ERR_INVALID;
+    if (!n_frames) return OFDM_OK;
+    DeviceGuard dev_guard(c->device);
+    ChannelParams p;
+    p.tx = reinterpret_cast<const float2 *>(tx); p.n_frames = n_frames; p.tx_stride = tx_stride; p.tx_len = tx_len;
+    p.snr_lin = std::pow(10.0, snr_db / 10.0); // channel.rs:40
+    p.timing_error = timing_error != 0; p.seed = seed; p.delay = delay; p.f_delta_in = f_delta_in;
+    p.out = reinterpret_cast<float2 *>(out); p.out_stride = out_stride; p.out_len = out_len; p.f_delta_out = f_delta_out;
+    for (int i = 0; i < 64; i++)
+        if (kChannelTaps[i] != 0.0 && p.n_taps < 16) { p.tap_idx[p.n_taps] = i; p.tap_val[p.n_taps] = (float)kChannelTaps[i]; p.n_taps++; }
+    HIP_TRY(c, run_channel(p, c->num_cu, c->stream));
+    return OFDM_OK;
+}
+
 int ofdm_hbm_read_probe(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_symbols, int32_t pattern) {
     if (!c || n_symbols < 0 || pattern < 0 || pattern > 2 || (n_symbols && !in)) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);

@@ -51,6 +51,27 @@ double orc_uniform_pm1(uint64_t *state) { return orc_uniform_01(state) * 2.0 - 1
 /* ------------------------------------------------------------------ FFT (rustfft contract: unnormalised DFT) */
 static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+/* Twiddle policy.  Default (cache off): every transform takes its twiddles from libm, as the reference builds a new
+ * FftPlanner + plan (twiddle generation included) on EVERY call (signals/mod.rs:41-58) -- the "ref-faithful" CPU baseline.
+ * orc_set_fft_cache(1): per-thread tables exp(-2 pi i k / n), k < n/2, built once per size -- the "ref-optimised" baseline.
+ * Results are bit-identical either way: k/len and (k n/len)/n are the same double (n/len is a power of two). */
+static int g_fft_cache = 0;
+void orc_set_fft_cache(int on) { g_fft_cache = on; }
+static __thread oc64 *t_fft_tab[32];
+static const oc64 *fft_table(int n) {
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+    if (!t_fft_tab[lg]) {
+        oc64 *t = (oc64 *)malloc(sizeof(oc64) * (size_t)(n / 2 > 0 ? n / 2 : 1));
+        for (int k = 0; k < n / 2; k++) {
+            double ang = -2.0 * M_PI * (double)k / (double)n;
+            t[k] = c_new(cos(ang), sin(ang));
+        }
+        t_fft_tab[lg] = t; /* lives as long as the thread */
+    }
+    return t_fft_tab[lg];
+}
+
 static void fft_pow2(oc64 *x, int n, int inverse) {
     /* iterative radix-2 DIT, twiddles from libm per stage index (no recurrence, keeps 1e-15 accuracy) */
     for (int i = 1, j = 0; i < n; i++) {
@@ -60,11 +81,16 @@ static void fft_pow2(oc64 *x, int n, int inverse) {
         if (i < j) { oc64 t = x[i]; x[i] = x[j]; x[j] = t; }
     }
     double sgn = inverse ? 1.0 : -1.0;
+    const oc64 *tab = g_fft_cache ? fft_table(n) : NULL;
     for (int len = 2; len <= n; len <<= 1) {
         int half = len >> 1;
         for (int k = 0; k < half; k++) {
-            double ang = sgn * 2.0 * M_PI * (double)k / (double)len;
-            oc64 w = c_new(cos(ang), sin(ang));
+            oc64 w;
+            if (tab) { w = tab[k * (n / len)]; if (inverse) w.im = -w.im; }
+            else {
+                double ang = sgn * 2.0 * M_PI * (double)k / (double)len;
+                w = c_new(cos(ang), sin(ang));
+            }
             for (int i = k; i < n; i += len) {
                 oc64 u = x[i], v = c_mul(x[i + half], w);
                 x[i] = c_add(u, v);

@@ -38,6 +38,9 @@ double orc_uniform_pm1(uint64_t *state); /* U(-1,1): ((z>>11) * 2^-53) * 2 - 1 *
 double orc_uniform_01(uint64_t *state);  /* U(0,1):  (z>>11) * 2^-53 */
 
 /* ---- signals/mod.rs primitives */
+/* 0 (default): twiddles from libm on every transform, like the reference's planner-per-call; 1: per-thread cached tables.
+ * Bit-identical results; only the CPU-baseline timing differs. */
+void orc_set_fft_cache(int on);
 void orc_fft(oc64 *x, int n, int inverse);          /* mod.rs:27-58 (inverse scales by 1/n) */
 void orc_fft_shift(oc64 *x, int n);                 /* mod.rs:61-77  */
 void orc_ifft_shift(oc64 *x, int n);                /* mod.rs:80-95  */

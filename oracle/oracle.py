@@ -74,6 +74,12 @@ def _u8(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_fft_cache(on: bool):
+    """False (default): libm twiddles on every transform (the reference re-plans per call, signals/mod.rs:41-58);
+    True: cached per-thread tables.  Same results bit for bit."""
+    lib().orc_set_fft_cache(C.c_int(int(on)))
+
+
 def cx(x) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(x, dtype=np.complex128))
 

@@ -221,3 +221,15 @@ def test_host_constants_match_reference_closed_forms(orc):
     assert api.locking_signal(80)[0] == 0.375
     np.testing.assert_array_equal(api.preamble(80), orc.default_preamble(80))
     np.testing.assert_array_equal(api.training_signals(64), orc.default_training(64))
+
+
+def test_channel_taps_are_the_reference_table(ofdm, orc):
+    """CHANNEL (src/channel.rs:26-31) as the library holds it == the oracle's table == the KAT fixture (taps 8..18)."""
+    import json
+    lib = ofdm.load()
+    taps = np.zeros(64)
+    assert lib.ofdm_channel_taps(taps.ctypes.data) == 0
+    np.testing.assert_array_equal(taps, orc.channel_taps())
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")))["channel_taps_8_18"]["taps"]
+    np.testing.assert_allclose(taps[8:19], kat, atol=0)
+    assert lib.ofdm_channel_taps(None) == -1

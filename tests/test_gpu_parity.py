@@ -630,6 +630,80 @@ def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod,
             assert int((one["status"] == 0).sum()) >= 36 and int((one["status"] == -2).sum()) >= 6
 
 
+# ------------------------------------------------------------------ a24: channel (src/channel.rs:33-74) on the GPU
+def test_channel_batch_matches_the_oracle(api, orc):
+    """ofdm_channel_batch against orc_channel with the same SplitMix64 streams: FIR CHANNEL, CFO exp(+j f (i+1)) with
+    f = pi U(0,1)/80, uniform noise scaled by the COMPLEX pseudo-variance; the drawn CFO bit for bit, samples <= 1e-6
+    (f32 output of an f64 computation)."""
+    rng = np.random.default_rng(24)
+    ctx = api.Context(modulation=api.QPSK)
+    frames = np.stack([orc.encode(bytes(rng.integers(0, 256, 400, dtype=np.uint8)), False, orc.QPSK) for _ in range(5)])
+    x32 = fc32(frames)
+    for snr, te in ((30.0, False), (30.0, True), (12.5, True)):
+        y, fd = ctx.channel_batch(dev(ctx, x32), snr_db=snr, timing_error=te, seed=77, want_f_delta=True)
+        y, fd = host(y), host(fd)
+        assert y.shape == (5, frames.shape[1] + 63)
+        for f in range(5):
+            want, wfd = orc.channel(wide(x32[f]), snr, te, seed=77 + f)
+            assert fd[f] == wfd
+            assert rel_err(y[f], want) <= 1e-6
+    # the MATLAB listing of conv((1-1i) ones(16), CHANNEL) (channel.rs:99-177), noise pushed below f32 resolution
+    ones = np.full((1, 16), 1 - 1j, np.complex64)
+    y = host(ctx.channel_batch(dev(ctx, ones), snr_db=300.0))[0]
+    want = orc.convolve(wide(ones[0]), orc.channel_taps())
+    assert rel_err(y, want) <= 1e-6
+    assert abs(y[8].real - (-0.1912)) < 3e-4 and abs(y[9].real - 0.7404) < 3e-4 and abs(y[10].real - 1.0225) < 3e-4
+    # taps table = the reference's
+    taps = np.zeros(64)
+    assert ctx.lib.ofdm_channel_taps(taps.ctypes.data) == 0
+    np.testing.assert_array_equal(taps, orc.channel_taps())
+
+
+def test_channel_batch_placement_and_cfo_override(api, orc):
+    """The test-bench extensions: per-frame delay inside a longer slot, explicit (signed) CFO.  With the noise pushed
+    below f32 resolution the slot equals the oracle's noiseless channel output shifted by the delay; with noise on, the
+    samples outside the channel output carry noise only and the whole chain decodes (config-3 synthesis)."""
+    import torch
+    rng = np.random.default_rng(25)
+    ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
+    pays = rng.integers(0, 256, (6, 560), dtype=np.uint8)
+    tx = ctx.encode_batch(dev(ctx, pays))
+    delay = torch.tensor([0, 1, 17, 33, 64, 5], dtype=torch.int32)
+    fd = torch.tensor([0.0, 0.01, -0.02, 0.035, -0.037, 0.0], dtype=torch.float64)
+    span = 2176
+    y = host(ctx.channel_batch(tx, snr_db=300.0, seed=3, delay=delay, f_delta=fd, span=span))
+    txh = host(tx)
+    for f in range(6):
+        c = np.convolve(wide(txh[f]), orc.channel_taps())[: txh.shape[1] + 63]
+        c = c * np.exp(1j * float(fd[f]) * np.arange(1, c.size + 1))
+        want = np.zeros(span, np.complex128)
+        d = int(delay[f])
+        m = min(c.size, span - d)
+        want[d:d + m] = c[:m]
+        assert rel_err(y[f], want) <= 1e-6
+    y = ctx.channel_batch(tx, snr_db=30.0, seed=4, delay=delay, f_delta=fd, span=span)
+    yh = host(y)
+    assert np.all(np.abs(yh[2][:17]) > 0) and np.abs(yh[2][:17]).max() < 0.05     # noise only before the frame
+    res = ctx.decode_batch(y, max_symbols=ctx.data_symbols(560))
+    st = host(res["status"])
+    assert np.all(st == 0)
+    for f in range(6):
+        w = orc.decode_sc(wide(yh[f]), True, orc.QAM64, 64, max_symbols=16)
+        assert host(res["offset"])[f] == w["offset"] and abs(host(res["f_delta"])[f] - w["f_delta"]) <= 1e-9
+        assert abs(host(res["f_delta"])[f] - float(fd[f])) < 2e-3               # the estimate tracks the injected CFO
+
+
+def test_loopback_through_the_gpu_channel(api, orc):
+    """examples/lab3a.rs / lab3b.rs entirely on the GPU: encode! -> channel! -> decode! (QPSK, no guard bands, 30 dB)."""
+    data = bytes((i * 11 + 5) % 253 for i in range(400))
+    tx = api.encode(data, False, api.QPSK)
+    for te in (False, True):
+        rx = api.channel(tx, 30.0, te, seed=9)
+        assert rx.size == tx.size + 63
+        got = api.decode(rx, False, api.QPSK, cfo_mode=api.CFO_ABS)
+        assert got == data and orc.analysis(data, got) == (0, 0, 0.0)
+
+
 def test_decode_errors(api, orc):
     # "Input not long enough, bailing early" (receiver.rs:27-29) and no-sync
     rng = np.random.default_rng(4)
