@@ -1,22 +1,62 @@
-"""Small workload for rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE): one calibration kernel with a known byte
-count in the same access pattern (batched FFT: reads and writes n*512 B with 8-B-per-lane accesses), the config-2
-RX-demod kernel, and the Schmidl-Cox kernel on config-3 shaped frames.  Inputs exceed the 256 MiB Infinity Cache."""
-import os, sys
+"""Workload for the rocprofv3 --pmc passes (tools/profile_round.sh): one calibration kernel with a known byte count in the
+hot kernels' 8-byte-per-lane access pattern (batched FFT: reads and writes n*512 B), then every kernel the bench times, on
+PACKET frames (the library's TX through its GPU channel model), at sizes beyond the 256 MiB Infinity Cache:
+  cfg2  k_demod64                      cfg3  k_sc_cf + k_sc_post + k_rx_prepare + k_rxframe64, and the one-pass k_sc_cf<..,6,true>
+  cfg4  Schmidl-Cox for L = 1280 + k_rxframe1024 + k_rx_finish        cfg5  k_tx4096, k_demod4096
+Prints the byte counts the summaries are divided by."""
+import json, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ofdm_amd import api
+from tools import bench_cfg3, bench_large_n
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+info = {"frames_cfg2_cfg3": n}
 ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
-x = torch.view_as_complex(torch.randn((n, 16 * 80, 2), device="cuda") * 0.1).contiguous()   # cfg2 shape
-out = torch.empty((n, 16 * 36), dtype=torch.uint8, device="cuda")
 v = torch.view_as_complex(torch.randn((n * 16, 64, 2), device="cuda")).contiguous()         # FFT calibration
 vo = torch.empty_like(v)
-y = torch.view_as_complex(torch.randn((n, 2176, 2), device="cuda") * 0.1).contiguous()      # cfg3 shape
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+pay = torch.randint(0, 256, (n, 16 * 36), dtype=torch.uint8, device="cuda", generator=g)
+x2 = ctx.prefix_block(ctx.encode_block(ctx.modulate(pay.view(-1)).view(-1, 48))).view(n, 16 * 80)  # cfg2 shape
+out2 = torch.empty((n, 16 * 36), dtype=torch.uint8, device="cuda")
+x3, p3 = bench_cfg3.synth(api, torch, ctx, n)
 for _ in range(2):
     ctx.fft(v, out=vo)
-    ctx.rx_demod(x, syms_per_frame=16, out=out)
-    ctx.sc_correlate(y)
+    ctx.rx_demod(x2, syms_per_frame=16, out=out2)
+    ctx.sc_correlate(x3)
+    ctx.decode_batch(x3, max_symbols=16)
+    os.environ["OFDM_ONE_PASS_RX"] = "1"
+    ctx.decode_batch(x3, max_symbols=16)
+    os.environ.pop("OFDM_ONE_PASS_RX")
+    ctx.encode_batch(p3)
 torch.cuda.synchronize()
-print("frames", n, "fft_bytes_each_way", n * 16 * 512, "demod_alg_read", n * 16 * 640, "demod_fetched_expected", n * 16 * 512,
-      "demod_write", n * 16 * 36, "sc_read", n * 2176 * 8)
+info.update(fft_bytes_each_way=n * 16 * 512, demod_alg_read=n * 16 * 640, demod_write=n * 16 * 36, cfg3_capture_bytes=n * 2176 * 8,
+            cfg3_payload_bytes=n * 560, tx_frame_bytes=n * 2080 * 8)
+del v, vo, x2, out2, x3, p3
+torch.cuda.empty_cache()
+# cfg4: a 16 Ki-frame ring (2.4 GB)
+c4 = api.Context(n_fft=1024, modulation=api.QAM64, guard_bands=True, ecc=api.ECC_HAMMING74)
+n4 = 16384
+pay4 = torch.randint(0, 256, (n4, bench_large_n.CFG4_NBYTES), dtype=torch.uint8, device="cuda", generator=g)
+tx4 = c4.encode_batch(pay4)
+d = torch.randint(1, 65, (n4,), device="cuda", generator=g, dtype=torch.int32)
+fd = (torch.rand((n4,), device="cuda", generator=g, dtype=torch.float64) * 1.9 - 0.95) * math.pi / c4.S
+x4 = c4.channel_batch(tx4, snr_db=40.0, seed=44, delay=d, f_delta=fd, span=tx4.shape[1] + 256)
+for _ in range(2):
+    c4.decode_batch(x4, max_symbols=4)
+    c4.decode_batch(x4, max_symbols=4, n_lags=2048)
+torch.cuda.synchronize()
+info.update(frames_cfg4=n4, cfg4_capture_bytes=n4 * x4.shape[1] * 8)
+del tx4, x4
+torch.cuda.empty_cache()
+# cfg5: 32 Ki symbols (1.3 GB)
+c5 = api.Context(n_fft=4096, modulation=api.QAM256, guard_bands=True)
+n5 = 32768
+pay5 = torch.randint(0, 256, (n5 * c5.bytes_per_symbol,), dtype=torch.uint8, device="cuda", generator=g)
+out5 = torch.empty((1, pay5.numel()), dtype=torch.uint8, device="cuda")
+for _ in range(2):
+    x5 = c5.tx_symbols(pay5)
+    c5.rx_demod(x5.view(1, -1), syms_per_frame=n5, out=out5)
+torch.cuda.synchronize()
+info.update(symbols_cfg5=n5, cfg5_sample_bytes=n5 * 5120 * 8, cfg5_payload_bytes=int(pay5.numel()))
+print(json.dumps(info))

@@ -1,28 +1,33 @@
 #!/bin/bash
-# Round profile set (run on the GPU box through gpurun, from the repo root):
-#   1. bench.py as the driver runs it                      -> gpurun_out/prof/bench.json
-#   2. the same command under rocprofv3 --kernel-trace     -> gpurun_out/prof/bench_kernel_stats_ofdm_only.csv
-#   3. separate --pmc passes on tools/pmc_probe.py         -> gpurun_out/prof/pmc_*.tsv
+# Round profile set (run on the GPU box through gpurun, from the repo root; ROUND=r02 names the files):
+#   1. bench.py as the driver runs it                      -> gpurun_out/prof/${ROUND}_bench.json
+#   2. the same command under rocprofv3 --kernel-trace     -> ${ROUND}_bench_kernel_stats_ofdm_only.csv
+#   3. separate --pmc passes on tools/pmc_probe.py         -> ${ROUND}_pmc_*.tsv  (FETCH_SIZE / WRITE_SIZE / SQ sets, never
+#      combined with a trace: MI355X_MICROARCH.md, HBM + rocprofv3 sections)
 # rocprofv3 writes its (large) traces under /tmp; only the summaries are copied back.
 set -o pipefail
+ROUND=${ROUND:-r02}
 OUT="$PWD/gpurun_out/prof"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout -k 10 400 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
-echo "bench done" 
-( cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 "$OLDPWD/bench.py" > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof_kt.err" ) || exit 2
+BENCH_ARGS=${BENCH_ARGS:-}
+if [ -z "$SKIP_BENCH" ]; then
+timeout -k 10 900 python3 bench.py $BENCH_ARGS > "$OUT/${ROUND}_bench.json" 2> "$OUT/${ROUND}_bench.err" || exit 1
+echo "bench done"
+( cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 "$OLDPWD/bench.py" $BENCH_ARGS > "$OUT/${ROUND}_bench_under_rocprof.json" 2> "$OUT/${ROUND}_rocprof_kt.err" ) || exit 2
 f=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1)
 test -n "$f" || exit 3
-( head -1 "$f"; grep "ofdm::" "$f" ) > "$OUT/bench_kernel_stats_ofdm_only.csv"
+( head -1 "$f"; grep "ofdm::" "$f" ) > "$OUT/${ROUND}_bench_kernel_stats_ofdm_only.csv"
 echo "kernel trace done"
+fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$c -- python3 "$OLDPWD/tools/pmc_probe.py" > "$OUT/pmc_$c.log" 2>&1 ) || exit 4
+  ( cd /tmp && timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$c -- python3 "$OLDPWD/tools/pmc_probe.py" > "$OUT/${ROUND}_pmc_$c.log" 2>&1 ) || exit 4
   echo "pmc $c done"
 done
-python3 tools/pmc_summary.py $(find /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE -name "*counter_collection.csv") > "$OUT/pmc_fetch_write_summary.tsv"
+python3 tools/pmc_summary.py $(find /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE -name "*counter_collection.csv") > "$OUT/${ROUND}_pmc_fetch_write_summary.tsv"
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  ( cd /tmp && timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "/tmp/prof_sq_$tag" -- python3 "$OLDPWD/tools/pmc_probe.py" > "$OUT/pmc_sq_$tag.log" 2>&1 ) || exit 5
+  ( cd /tmp && timeout -k 10 400 rocprofv3 --pmc $grp --output-format csv -d "/tmp/prof_sq_$tag" -- python3 "$OLDPWD/tools/pmc_probe.py" > "$OUT/${ROUND}_pmc_sq_$tag.log" 2>&1 ) || exit 5
   echo "pmc $tag done"
 done
-python3 tools/pmc_summary.py $(find /tmp/prof_sq_* -name "*counter_collection.csv") > "$OUT/pmc_sq_summary.tsv"
+python3 tools/pmc_summary.py $(find /tmp/prof_sq_* -name "*counter_collection.csv") > "$OUT/${ROUND}_pmc_sq_summary.tsv"
 echo "all done"
