@@ -117,6 +117,22 @@ struct ScRxFused {
 bool sc_rx_fused_ok(const ScParams &p, const ScRxFused &rx);
 hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st, const ScRxFused *rx = nullptr,
                        const int32_t **slow_list = nullptr, const int32_t **slow_count = nullptr);
+// long periods (N >= 128): chunk sums + bounded exact search (kernels_scbig.hip)
+struct ScBigParams {
+    const float2 *in = nullptr;
+    long long n_frames = 0, frame_stride = 0, frame_len = 0, n_lags = 0;
+    int L = 0, W = 0, C = 0;       // period, window, chunk = L / 8
+    int nch = 0, nch_pad = 0;      // chunks per frame; row length of the workspace (>= nch + 1)
+    int tiles_per_frame = 0;
+    double threshold = 0.5;
+    double *ws = nullptr;          // [n_frames][3][nch_pad]: chunk totals, then exclusive prefixes, of q.re, q.im, e
+    int32_t *d_hat = nullptr;
+    double *f_delta = nullptr;
+    float *metric = nullptr;
+};
+bool sc_big_ok(const ScParams &p);
+size_t sc_big_workspace_bytes(const ScParams &p);
+hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_t st);
 hipError_t run_sc_min_cross(const long long *cross, int tiles_per_frame, long long n_frames, int32_t *d1, hipStream_t st);
 hipError_t run_freq_correction(const float2 *in, long long n_pairs, long long stride, long long right_offset, int L,
                                double *f_delta, hipStream_t st);

@@ -1,0 +1,348 @@
+// kernels_scbig.hip -- Schmidl-Cox timing for LONG periods (L = S >= 160: N >= 128), where neither the frame nor even one
+// correlation window (W + L samples: 164 KB at N = 4096) fits in LDS.
+//
+// The sliding sums are prefix differences:
+//     P(d) = Q[d + W] - Q[d],   E(d) = Ep[d + W] - Ep[d],   R(d) = Ep[d + W + L] - Ep[d + L],
+//     Q[n] = sum_{m<n} conj(r[m]) r[m+L],  Ep[n] = sum_{m<n} |r[m]|^2.
+// so the capture is read ONCE to form chunk sums of q and e (chunks of C = L/8 samples, f64: products of f32 samples are
+// exact in f64), and the per-lag metric is only evaluated where it can matter:
+//   k_scb_chunks   one workgroup per (frame, tile of 2560 samples): the tile and its partner tile L samples later are staged
+//                  coalesced into LDS, every thread sums one 10-sample micro-chunk in f64, C/10 neighbouring lanes are
+//                  combined with wave shuffles, chunk totals go to a small per-frame workspace (24 B per chunk: 2 % of the
+//                  capture).  HBM roofline: 8 B/sample read once (the partner tile is an L2 / Infinity-Cache re-read).
+//   k_scb_fine     one workgroup per frame: f64 prefix sums over the chunk totals, exact sums at every chunk boundary, and
+//                  for every chunk an upper bound of the metric over its C lags,
+//                      |P(d)| <= |P0| + 1/2 (Te[c] + Te[c+L] + Te[c+W] + Te[c+W+L]),  E(d) >= E0 - Te[c],  R(d) >= R0 - Te[c+L],
+//                  so only chunks whose bound reaches the threshold are searched for the first crossing d1, and only chunks
+//                  whose bound reaches the best exact value found so far are searched for the peak over [d1, d1 + W].
+//                  A search evaluates a tile of 1280 lags exactly: four 1280-sample segments (at d0, d0+L, d0+W, d0+W+L) are
+//                  staged into LDS, each thread slides the three sums over its 10 lags in f64 from the tile's boundary sums
+//                  (prefix differences), a workgroup scan chains the threads.
+// Every decision is taken on f64 sums, as k_sc_tile does: timing indices equal the f64 oracle's except on ties below f64
+// resolution.  Works for any N in 128..4096 (the LDS footprint does not depend on L) and any capture of up to 2047 chunks.
+#include "device_common.hpp"
+#include "kernels.hpp"
+#include <limits.h>
+
+namespace ofdm {
+
+namespace {
+
+constexpr int B_TILE = 2560;   // samples per chunk-sum tile (256 threads x 10)
+constexpr int F_TILE = 1280;   // lags per fine tile (128 threads x 10)
+constexpr int F_WG = 128;
+
+struct BSums { double pr, pi, e, r; };
+__device__ __forceinline__ BSums bs_add(BSums a, BSums b) { return BSums{a.pr + b.pr, a.pi + b.pi, a.e + b.e, a.r + b.r}; }
+struct BCand { double num, den, pr, pi; int lag; };
+// first maximum wins, whatever the order of discovery: strictly greater replaces; equal replaces only from a lower lag
+__device__ __forceinline__ BCand bc_pick(BCand a, BCand b) {
+    const double lhs = b.num * a.den, rhs = a.num * b.den;
+    return (lhs > rhs || (lhs == rhs && b.lag < a.lag)) ? b : a;
+}
+__device__ __forceinline__ BCand bc_shfl_xor(BCand a, int d) {
+    return BCand{__shfl_xor(a.num, d, 64), __shfl_xor(a.den, d, 64), __shfl_xor(a.pr, d, 64), __shfl_xor(a.pi, d, 64),
+                 __shfl_xor(a.lag, d, 64)};
+}
+
+// coalesced staging of `count` samples starting at sample `first` of a frame into LDS, zero past the capture
+__device__ __forceinline__ void stage_segment(cf *dst, const cf *frame, long long first, int count, long long frame_len, int tid, int nthr) {
+    const cf *src = frame + first;
+    const long long avail = frame_len - first; // may be <= 0
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int i = tid; i < count / 2; i += nthr) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (2 * i + 1 < avail) x = s4[i];
+            else if (2 * i < avail) { const cf y = src[2 * i]; x.x = y.x; x.y = y.y; }
+            d4[i] = x;
+        }
+    } else {
+        for (int i = tid; i < count; i += nthr) dst[i] = i < avail ? src[i] : make_float2(0.f, 0.f);
+    }
+}
+
+} // namespace
+
+// ---- chunk totals: ws[f][0 .. nch) = sum q.re, [nch .. 2 nch) = sum q.im, [2 nch .. 3 nch) = sum e   (doubles)
+__global__ __launch_bounds__(256) void k_scb_chunks(ScBigParams p) {
+    __shared__ __align__(16) cf seg_a[B_TILE];
+    __shared__ __align__(16) cf seg_b[B_TILE];
+    const int tid = threadIdx.x;
+    const int k = p.C / 10;                  // micro-chunks per chunk: N / 64, a power of two <= 64
+    const long long items = p.n_frames * (long long)p.tiles_per_frame;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const long long f = it / p.tiles_per_frame;
+        const int tile = (int)(it - f * p.tiles_per_frame);
+        const cf *frame = p.in + f * p.frame_stride;
+        const long long t0 = (long long)tile * B_TILE;
+        __syncthreads(); // the previous item's readers are done
+        stage_segment(seg_a, frame, t0, B_TILE, p.frame_len, tid, 256);
+        stage_segment(seg_b, frame, t0 + p.L, B_TILE, p.frame_len, tid, 256);
+        __syncthreads();
+        double qr = 0.0, qi = 0.0, e = 0.0;
+        {
+            const float4 *pa = reinterpret_cast<const float4 *>(seg_a + tid * 10), *pb = reinterpret_cast<const float4 *>(seg_b + tid * 10);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const float4 x = pa[i], y = pb[i];
+                const double ar = x.x, ai = x.y, br = y.x, bi = y.y, cr = x.z, ci = x.w, dr = y.z, di = y.w;
+                qr += ar * br + ai * bi; qi += ar * bi - ai * br; e += ar * ar + ai * ai;
+                qr += cr * dr + ci * di; qi += cr * di - ci * dr; e += cr * cr + ci * ci;
+            }
+        }
+        for (int sft = 1; sft < k; sft <<= 1) { // k consecutive lanes -> one chunk (k <= 64: inside the wavefront)
+            qr += __shfl_xor(qr, sft, 64); qi += __shfl_xor(qi, sft, 64); e += __shfl_xor(e, sft, 64);
+        }
+        if ((tid & (k - 1)) == 0) {
+            const int c = (int)(t0 / p.C) + tid / k;
+            if (c < p.nch) {
+                double *w = p.ws + f * 3LL * p.nch_pad;
+                w[c] = qr; w[p.nch_pad + c] = qi; w[2 * p.nch_pad + c] = e;
+            }
+        }
+    }
+}
+
+// ---- prefix sums, chunk bounds, first crossing, peak
+__global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf *s0 = reinterpret_cast<cf *>(smem);       // [F_TILE + 16] samples at d0 ..
+    cf *s1 = s0 + F_TILE + 16;                   // ... at d0 + L
+    cf *s2 = s1 + F_TILE + 16;                   // ... at d0 + W
+    cf *s3 = s2 + F_TILE + 16;                   // ... at d0 + W + L
+    float *mub = reinterpret_cast<float *>(s3 + F_TILE + 16);    // [nch_pad] upper bound of M over the chunk's lags (rounded up)
+    BSums *wsum = reinterpret_cast<BSums *>(mub + p.nch_pad);    // [2] wave totals
+    BCand *wcand = reinterpret_cast<BCand *>(wsum + 2);          // [2]
+    int *wmin = reinterpret_cast<int *>(wcand + 2);              // [2]
+    int *shi = wmin + 2;                                         // [2] scratch
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = p.L, W = p.W, C = p.C, nch = p.nch, cL = L / C, cW = W / C;
+    const long long n = p.n_lags;
+    const int n_bound = (int)((n + C - 1) / C);  // chunks that own at least one searched lag
+    const double thr = p.threshold;
+
+    for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+        const cf *frame = p.in + f * p.frame_stride;
+        double *Qr = p.ws + f * 3LL * p.nch_pad, *Qi = Qr + p.nch_pad, *Ep = Qi + p.nch_pad;
+        __syncthreads();
+        // ---- exclusive prefix sums over the chunk totals, in place (wave 0; 64 chunks per step, carry in registers)
+        if (wave == 0) {
+            double cr = 0.0, ci = 0.0, ce = 0.0;
+            for (int base = 0; base < nch; base += 64) {
+                const int c = base + lane;
+                double a = c < nch ? Qr[c] : 0.0, b = c < nch ? Qi[c] : 0.0, e = c < nch ? Ep[c] : 0.0;
+                double ia = a, ib = b, ie = e;
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    const double oa = __shfl_up(ia, sft, 64), ob = __shfl_up(ib, sft, 64), oe = __shfl_up(ie, sft, 64);
+                    if (lane >= sft) { ia += oa; ib += ob; ie += oe; }
+                }
+                if (c < nch) { Qr[c] = cr + (ia - a); Qi[c] = ci + (ib - b); Ep[c] = ce + (ie - e); }
+                cr += __shfl(ia, 63, 64); ci += __shfl(ib, 63, 64); ce += __shfl(ie, 63, 64);
+            }
+            if (lane == 0) { Qr[nch] = cr; Qi[nch] = ci; Ep[nch] = ce; } // entry nch = the total
+        }
+        __threadfence_block();
+        __syncthreads();
+        // exact sums at chunk boundary c (lag c C)
+        auto boundary = [&](int c) -> BSums {
+            return BSums{Qr[c + cW] - Qr[c], Qi[c + cW] - Qi[c], Ep[c + cW] - Ep[c], Ep[c + cW + cL] - Ep[c + cL]};
+        };
+        // ---- upper bound of the metric over each chunk's lags
+        for (int c = tid; c < n_bound; c += F_WG) {
+            const BSums b = boundary(c);
+            const double te0 = Ep[c + 1] - Ep[c], teL = Ep[c + cL + 1] - Ep[c + cL], teW = Ep[c + cW + 1] - Ep[c + cW],
+                         teWL = Ep[c + cW + cL + 1] - Ep[c + cW + cL];
+            const double ub = sqrt(b.pr * b.pr + b.pi * b.pi) * (1.0 + 1e-12) + 0.5 * (te0 + teL + teW + teWL);
+            const double elo = b.e - te0, rlo = b.r - teL;
+            float m = 3.0e38f;
+            if (elo > 0.0 && rlo > 0.0) { const double q = ub * ub / (elo * rlo) * (1.0 + 1e-9); m = q < 3.0e38 ? (float)q * 1.000001f : 3.0e38f; }
+            if (!(ub > 0.0)) m = 0.f; // an all-zero neighbourhood: no lag of this chunk has a defined metric
+            mub[c] = m;
+        }
+        __syncthreads();
+
+        // Exact evaluation of the F_TILE lags from d0 (a chunk boundary): first crossing in [lo, hi] (if want_cross), then the
+        // first maximum over [max(lo, crossing), hi].  Returns the crossing (INT_MAX: none) through *cross_out.
+        auto eval_tile = [&](long long d0, long long lo, long long hi, bool want_cross, long long &cross_out, BCand &best) {
+            __syncthreads();
+            stage_segment(s0, frame, d0, F_TILE + 16, p.frame_len, tid, F_WG);
+            stage_segment(s1, frame, d0 + L, F_TILE + 16, p.frame_len, tid, F_WG);
+            stage_segment(s2, frame, d0 + W, F_TILE + 16, p.frame_len, tid, F_WG);
+            stage_segment(s3, frame, d0 + W + L, F_TILE + 16, p.frame_len, tid, F_WG);
+            __syncthreads();
+            const int a0 = tid * 10;
+            BSums pre[10];
+            {
+                BSums run = BSums{0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const cf x0 = s0[a0 + j], x1 = s1[a0 + j], x2 = s2[a0 + j], x3 = s3[a0 + j];
+                    const double r0 = x0.x, i0 = x0.y, r1 = x1.x, i1 = x1.y, r2 = x2.x, i2 = x2.y, r3 = x3.x, i3 = x3.y;
+                    run.pr += (r2 * r3 + i2 * i3) - (r0 * r1 + i0 * i1);
+                    run.pi += (r2 * i3 - i2 * r3) - (r0 * i1 - i0 * r1);
+                    run.e += (r2 * r2 + i2 * i2) - (r0 * r0 + i0 * i0);
+                    run.r += (r3 * r3 + i3 * i3) - (r1 * r1 + i1 * i1);
+                    pre[j] = run;
+                }
+            }
+            BSums inc = pre[9];
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const BSums o = BSums{__shfl_up(inc.pr, sft, 64), __shfl_up(inc.pi, sft, 64), __shfl_up(inc.e, sft, 64), __shfl_up(inc.r, sft, 64)};
+                if (lane >= sft) inc = bs_add(inc, o);
+            }
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            BSums base = boundary((int)(d0 / C));
+            if (wave == 1) base = bs_add(base, wsum[0]);
+            {
+                const BSums ex = BSums{__shfl_up(inc.pr, 1, 64), __shfl_up(inc.pi, 1, 64), __shfl_up(inc.e, 1, 64), __shfl_up(inc.r, 1, 64)};
+                if (lane > 0) base = bs_add(base, ex);
+            }
+            // base = sums at lag d0 + a0
+            long long cross = LLONG_MAX;
+            if (want_cross) {
+                int mine = INT_MAX;
+#pragma unroll
+                for (int j = 9; j >= 0; --j) {
+                    const BSums x = j ? bs_add(base, pre[j - 1]) : base;
+                    const double num = x.pr * x.pr + x.pi * x.pi, den = x.e * x.r;
+                    const long long lag = d0 + a0 + j;
+                    if (lag >= lo && lag <= hi && den > 0.0 && num >= thr * den) mine = a0 + j;
+                }
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(mine, sft, 64); mine = o < mine ? o : mine; }
+                if (lane == 0) wmin[wave] = mine;
+                __syncthreads();
+                const int m = wmin[0] < wmin[1] ? wmin[0] : wmin[1];
+                if (m != INT_MAX) { cross = d0 + m; lo = cross; if (hi > cross + W) hi = cross + W; }
+                cross_out = cross;
+                if (m == INT_MAX) return; // wave-uniform: no crossing in this tile, nothing to maximise yet
+            }
+            BCand mineb = BCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const BSums x = j ? bs_add(base, pre[j - 1]) : base;
+                const double num = x.pr * x.pr + x.pi * x.pi, den = x.e * x.r;
+                const long long lag = d0 + a0 + j;
+                if (lag >= lo && lag <= hi && den > 0.0) mineb = bc_pick(mineb, BCand{num, den, x.pr, x.pi, (int)lag});
+            }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) mineb = bc_pick(mineb, bc_shfl_xor(mineb, sft));
+            if (lane == 0) wcand[wave] = mineb;
+            __syncthreads();
+            best = bc_pick(best, bc_pick(wcand[0], wcand[1]));
+        };
+
+        // ---- first crossing: chunks whose bound reaches the threshold, in lag order
+        long long d1 = LLONG_MAX, tile0 = 0;
+        BCand best = BCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
+        const float thr_f = (float)thr * 0.999999f;
+        int c = 0;
+        for (;;) {
+            // next flagged chunk >= c (all threads scan the same LDS table: wave-uniform result)
+            int cn = INT_MAX;
+            for (int i = c + tid; i < n_bound; i += F_WG) if (mub[i] >= thr_f) { cn = i; break; }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(cn, sft, 64); cn = o < cn ? o : cn; }
+            if (lane == 0) shi[wave] = cn;
+            __syncthreads();
+            cn = shi[0] < shi[1] ? shi[0] : shi[1];
+            __syncthreads();
+            if (cn == INT_MAX) break;
+            tile0 = (long long)cn * C;
+            long long cross;
+            eval_tile(tile0, tile0, n - 1, true, cross, best);
+            if (cross != LLONG_MAX) { d1 = cross; break; }
+            c = cn + F_TILE / C;
+        }
+        if (d1 == LLONG_MAX) {
+            if (tid == 0) { p.d_hat[f] = -1; if (p.f_delta) p.f_delta[f] = 0.0; if (p.metric) p.metric[f] = 0.f; }
+            continue;
+        }
+        // ---- peak over [d1, dend]: the crossing's tile is already in `best`; chunk boundaries inside the window are exact
+        //      candidates for free; a further tile is evaluated only if one of its chunks can still beat the best
+        const long long dend = d1 + W < n - 1 ? d1 + W : n - 1;
+        {
+            __syncthreads(); // every thread has merged the crossing tile's candidates out of wcand
+            BCand bb = BCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
+            for (int cb = (int)((d1 + C - 1) / C) + tid; (long long)cb * C <= dend; cb += F_WG) {
+                const BSums x = boundary(cb);
+                const double num = x.pr * x.pr + x.pi * x.pi, den = x.e * x.r;
+                if (den > 0.0) bb = bc_pick(bb, BCand{num, den, x.pr, x.pi, cb * C});
+            }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) bb = bc_pick(bb, bc_shfl_xor(bb, sft));
+            if (lane == 0) wcand[wave] = bb;
+            __syncthreads();
+            best = bc_pick(best, bc_pick(wcand[0], wcand[1]));
+            __syncthreads();
+        }
+        for (long long t = tile0 + F_TILE; t <= dend; t += F_TILE) {
+            const float need = (float)(best.num / best.den) * 0.999999f; // a chunk must be able to reach this to matter
+            bool any = false;
+            for (int i = (int)(t / C); i < n_bound && (long long)i * C <= dend && (long long)i * C < t + F_TILE; ++i) any |= mub[i] >= need;
+            if (!any) continue; // wave- and workgroup-uniform (same table, same best)
+            long long dummy;
+            eval_tile(t, d1, dend, false, dummy, best);
+        }
+        if (tid == 0) {
+            if (best.lag == INT_MAX) { p.d_hat[f] = -1; if (p.f_delta) p.f_delta[f] = 0.0; if (p.metric) p.metric[f] = 0.f; }
+            else {
+                p.d_hat[f] = best.lag;
+                if (p.f_delta) p.f_delta[f] = atan2(best.pi, best.pr) / (double)L;
+                if (p.metric) p.metric[f] = (float)(best.num / best.den);
+            }
+        }
+    }
+}
+
+// L = 8 C, C = 10 k with k = N / 64 a power of two <= 64; every searched lag's window inside nch chunks
+bool sc_big_ok(const ScParams &p) {
+    if (p.mode != 0 || p.L % 80 != 0 || p.W % p.L != 0) return false;
+    const int k = p.L / 80;
+    if (k < 2 || k > 64 || (k & (k - 1))) return false;
+    const int C = p.L / 8;
+    const long long nch = (p.n_lags + p.W + p.L + C - 1) / C + 1;
+    return nch <= 4096;
+}
+size_t sc_big_workspace_bytes(const ScParams &p) {
+    const int C = p.L / 8;
+    const long long nch = (p.n_lags + p.W + p.L + C - 1) / C + 1, pad = (nch + 1 + 7) / 8 * 8;
+    return (size_t)p.n_frames * 3 * (size_t)pad * sizeof(double);
+}
+hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_t st) {
+    if (p.n_frames <= 0) return hipSuccess;
+    ScBigParams q;
+    q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride; q.frame_len = p.frame_len; q.n_lags = p.n_lags;
+    q.L = p.L; q.W = p.W; q.C = p.L / 8; q.threshold = p.threshold;
+    q.nch = (int)((p.n_lags + p.W + p.L + q.C - 1) / q.C + 1);
+    q.nch_pad = (q.nch + 1 + 7) / 8 * 8;
+    q.tiles_per_frame = (int)(((long long)q.nch * q.C + B_TILE - 1) / B_TILE);
+    q.ws = reinterpret_cast<double *>(workspace);
+    q.d_hat = p.d_hat; q.f_delta = p.f_delta; q.metric = p.metric;
+    const long long items = p.n_frames * (long long)q.tiles_per_frame;
+    long long g1 = (long long)num_cu * 3; // 40 KB of LDS per workgroup
+    if (g1 > items) g1 = items;
+    hipLaunchKernelGGL(k_scb_chunks, dim3((unsigned)g1), dim3(256), 0, st, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds = (size_t)4 * (F_TILE + 16) * sizeof(float2) + (size_t)q.nch_pad * sizeof(float) + 2 * sizeof(BSums) +
+                       2 * sizeof(BCand) + 4 * sizeof(int) + 64;
+    if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scb_fine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    long long per_cu = (long long)(160 * 1024) / (long long)lds;
+    if (per_cu > 6) per_cu = 6;
+    long long g2 = (long long)num_cu * per_cu;
+    if (g2 > p.n_frames) g2 = p.n_frames;
+    hipLaunchKernelGGL(k_scb_fine, dim3((unsigned)g2), dim3(F_WG), lds, st, q);
+    return hipGetLastError();
+}
+
+} // namespace ofdm

@@ -567,6 +567,15 @@ static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame
         HIP_TRY(c, run_sc_fast(p, wsp, c->num_cu, c->stream));
         return OFDM_OK;
     }
+    // long periods (N >= 128): one streaming pass for chunk sums, then an exact search only where the chunk bounds allow a
+    // crossing / a new maximum (kernels_scbig.hip); LDS footprint independent of L, so N = 4096 works too
+    if (sc_big_ok(p) && getenv("OFDM_NO_SC_BIG") == nullptr) {
+        void *wsp;
+        int rc = ws_get(c, 6, sc_big_workspace_bytes(p), &wsp);
+        if (rc) return rc;
+        HIP_TRY(c, run_sc_big(p, wsp, c->num_cu, c->stream));
+        return OFDM_OK;
+    }
     if (sc_lds_bytes(p) > 160 * 1024) return OFDM_ERR_UNSUPPORTED; // window does not fit one CU's LDS
     const int CH = sc_tile_lags();
     const int64_t tiles = (n_lags + CH - 1) / CH;

@@ -630,6 +630,78 @@ def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod,
             assert int((one["status"] == 0).sum()) >= 36 and int((one["status"] == -2).sum()) >= 6
 
 
+# ------------------------------------------------------------------ EXT-3 for long periods (kernels_scbig.hip), EXT-4 decode up to N = 4096
+@pytest.mark.parametrize("n,mod,nbytes", [(128, 4, 300), (256, 6, 700), (512, 2, 500), (1024, 6, 1304), (2048, 4, 3000), (4096, 8, 9000)])
+def test_sc_correlate_and_decode_long_periods(api, orc, n, mod, nbytes):
+    """Schmidl-Cox for L = 160 .. 5120 (chunk sums + bounded exact search) against the oracle over ALL lags of the capture
+    and over a bounded search, on frames through the FIR channel with delay, CFO and noise, on noise-only captures and on a
+    capture cut inside the preamble; then the whole decode (N = 2048 / 4096 included: ADVICE r1).  Timing index, status and
+    offset bit-exact, CFO to 1e-9, bytes exact."""
+    rng = np.random.default_rng(7000 + n)
+    S = n + n // 4
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=True)
+    D = ctx.data_symbols(nbytes)
+    flen = ctx.frame_samples(nbytes)
+    span = (flen + 3 * S // 2) // 2 * 2
+    nf = 5 if n <= 1024 else 3
+    caps = []
+    for f in range(nf):
+        tx = orc.encode(bytes(rng.integers(0, 256, nbytes, dtype=np.uint8)), True, mod, n)
+        d = int(rng.integers(1, S))
+        fd = (rng.random() * 1.8 - 0.9) * np.pi / S
+        caps.append(through_channel(orc, rng, tx, span, d, fd, 32.0, data_start=10 * S))
+    caps.append(fc32(0.05 * (rng.standard_normal(span) + 1j * rng.standard_normal(span))))     # noise only
+    cut = caps[0].copy(); cut[int(3.5 * S):] = 0                                               # ends inside the preamble
+    caps.append(cut)
+    caps = np.stack(caps)
+    for lags in (0, 2 * S):
+        d_hat, f_delta, metric = (host(v) for v in ctx.sc_correlate(dev(ctx, caps), n_lags=lags))
+        for f in range(caps.shape[0]):
+            wd, wp, wm, wfd = orc.sc_sync(wide(caps[f]), L=S, window_reps=3, n_lags=lags, threshold=0.5)
+            assert d_hat[f] == wd, (n, lags, f, d_hat[f], wd)
+            if wd >= 0:
+                assert abs(f_delta[f] - wfd) <= 1e-9 and abs(metric[f] - wm) <= 1e-6 * max(1.0, wm)
+    res = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=D).items()}
+    for f in range(caps.shape[0]):
+        w = orc.decode_sc(wide(caps[f]), True, mod, n, max_symbols=D, want_soft=True)
+        assert res["status"][f] == w["status"], (n, f)
+        if w["status"] != 0:
+            continue
+        assert res["offset"][f] == w["offset"] and abs(res["f_delta"][f] - w["f_delta"]) <= 1e-9
+        got = bytes(res["bytes"][f][: res["len"][f]])
+        if got != w["bytes"]:
+            assert len(got) == len(w["bytes"])
+            gb = np.unpackbits(np.frombuffer(got, np.uint8), bitorder="little")
+            wb = np.unpackbits(np.frombuffer(w["bytes"], np.uint8), bitorder="little")
+            pts = np.unique((128 + np.nonzero(gb != wb)[0]) // mod)
+            from util import decision_margin
+            assert np.all(decision_margin(np.asarray(w["soft"])[pts], mod) < TOL), (n, f)
+    assert int((res["status"][:nf] == 0).sum()) == nf
+
+
+def test_bounded_search_clips_the_peak_window(api, orc):
+    """n_lags bounds the searched lags AND therefore the peak window [d1, min(d1 + W, n_lags - 1)] (include/ofdm_hip.h):
+    a frame whose true peak lies beyond n_lags - 1 gets a different (earlier) timing from a bounded search than from the
+    full one -- on the GPU exactly as in the oracle.  (This is why 8 of 262 144 round-1 config-3 frames decoded differently
+    with n_lags = 256: their first crossing came late enough for the clipped window to miss the peak.)"""
+    rng = np.random.default_rng(88)
+    ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
+    tx = orc.encode(bytes(rng.integers(0, 256, 560, dtype=np.uint8)), True, orc.QAM64, 64)
+    cap = through_channel(orc, rng, tx, 2400, 150, 0.01, 30.0, data_start=800)   # peak at 150 + 89 = 239
+    x = dev(ctx, cap.reshape(1, -1))
+    full = int(host(ctx.sc_correlate(x)[0])[0])
+    assert full == orc.sc_sync(wide(cap), 80, 3, 0, 0.5)[0] == 239
+    for lags in (200, 230, 239, 240, 256):
+        got = int(host(ctx.sc_correlate(x, n_lags=lags)[0])[0])
+        want = orc.sc_sync(wide(cap), 80, 3, lags, 0.5)[0]
+        assert got == want, (lags, got, want)
+        assert (got == full) == (lags >= 240)        # the window is clipped at lag n_lags - 1
+    # and the decode follows: status / offset / bytes equal the oracle's under the bounded search too
+    res = {k: host(v) for k, v in ctx.decode_batch(x, max_symbols=16, n_lags=230).items()}
+    w = orc.decode_sc(wide(cap), True, orc.QAM64, 64, sync_lags=230, max_symbols=16)
+    assert res["status"][0] == w["status"] and res["offset"][0] == w["offset"]
+
+
 # ------------------------------------------------------------------ a24: channel (src/channel.rs:33-74) on the GPU
 def test_channel_batch_matches_the_oracle(api, orc):
     """ofdm_channel_batch against orc_channel with the same SplitMix64 streams: FIR CHANNEL, CFO exp(+j f (i+1)) with
