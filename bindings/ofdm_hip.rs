@@ -19,7 +19,8 @@ pub struct ofdm_fc32 { pub re: f32, pub im: f32 }
 pub struct ofdm_params {
     pub n_fft: i32, pub cp_len: i32, pub modulation: i32, pub guard_bands: i32, pub ecc: i32,
     pub sync_window_reps: i32, pub sync_backoff: i32, pub cfo_mode: i32, pub sync_threshold: f32,
-    pub reserved: [i32; 7],
+    pub sync_mode: i32,
+    pub reserved: [i32; 6],
 }
 
 pub const OFDM_OK: c_int = 0;
@@ -84,6 +85,7 @@ extern "C" {
     pub fn ofdm_rx_decode_batch(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, n_frames: i64, frame_stride: i64, frame_len: i64,
                                 n_lags: i64, max_symbols: i32, out_dev: *mut u8, out_stride: i64, out_len_dev: *mut i32,
                                 status_dev: *mut i32, offset_dev: *mut i32, f_delta_dev: *mut f64, metric_dev: *mut f32) -> c_int;
+    pub fn ofdm_xcorr_batch(ctx: *mut ofdm_ctx, a_dev: *const ofdm_fc32, n_frames: i64, a_stride: i64, a_len: i64, b_dev: *const ofdm_fc32, nb: i32, idx_max_dev: *mut i32, peak_dev: *mut f32, out_dev: *mut ofdm_fc32, out_stride: i64) -> c_int;
     pub fn ofdm_channel_batch(ctx: *mut ofdm_ctx, tx_dev: *const ofdm_fc32, n_frames: i64, tx_stride: i64, tx_len: i64, snr_db: f64, timing_error: i32, seed: u64, delay_dev: *const i32, f_delta_in_dev: *const f64, out_dev: *mut ofdm_fc32, out_stride: i64, out_len: i64, f_delta_out_dev: *mut f64) -> c_int;
     pub fn ofdm_channel_taps(taps64: *mut f64) -> c_int;
     pub fn ofdm_hbm_read_probe(ctx: *mut ofdm_ctx, in_dev: *const ofdm_fc32, n_symbols: i64, pattern: i32) -> c_int;

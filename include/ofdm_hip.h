@@ -56,6 +56,7 @@ enum {
     OFDM_FRAME_OK = 0,
     OFDM_FRAME_SHORT = -1,  /* "Input not long enough, bailing early" (src/receiver.rs:27-29) */
     OFDM_FRAME_NOSYNC = -2, /* no lag reached the Schmidl-Cox threshold */
+    OFDM_FRAME_BADTIMING = -3, /* OFDM_SYNC_REFERENCE: offset = lag - 1 outside the capture (the reference panics in split_off, receiver.rs:25) */
     OFDM_FRAME_HEADER = -4  /* fewer than 16 decoded bytes (reference panics in drain, receiver.rs:88) */
 };
 
@@ -63,6 +64,10 @@ enum {
 enum { OFDM_MOD_BPSK = 1, OFDM_MOD_QPSK = 2, OFDM_MOD_QAM16 = 4, OFDM_MOD_QAM64 = 6, OFDM_MOD_QAM256 = 8 };
 enum { OFDM_ECC_NONE = 0, OFDM_ECC_HAMMING74 = 1 };
 enum { OFDM_CFO_OFF = 0, OFDM_CFO_SIGNED = 1, OFDM_CFO_ABS = 2 }; /* ABS = reference's abs() (receiver.rs:239) */
+/* timing / CFO detector of decode: the north star's Schmidl-Cox (default), or the reference's own pair -- cross-correlation
+ * with the locking signal (xcorr_fft, src/signals/mod.rs:186-217; offset = idx_max - N = lag - 1, src/receiver.rs:20-25) and
+ * frequency_correction on preamble repetitions 3 and 4 (src/receiver.rs:39, 231-240; always |.|) */
+enum { OFDM_SYNC_SCHMIDL_COX = 0, OFDM_SYNC_REFERENCE = 1 };
 
 typedef struct {
     int32_t n_fft;            /* sub-carriers: 64 (reference) .. 4096, power of two */
@@ -74,7 +79,8 @@ typedef struct {
     int32_t sync_backoff;     /* frame start = d_hat - L - backoff, default 4 */
     int32_t cfo_mode;         /* OFDM_CFO_* , default SIGNED */
     float sync_threshold;     /* packet-detect threshold on M(d), default 0.5 */
-    int32_t reserved[7];      /* must be zero */
+    int32_t sync_mode;        /* OFDM_SYNC_*, default SCHMIDL_COX (this slot was reserved[0] == 0: same layout, same default) */
+    int32_t reserved[6];      /* must be zero */
 } ofdm_params;
 
 /* ------------------------------------------------------------------ library / context */
@@ -169,6 +175,14 @@ int ofdm_rs255_decode(const uint8_t *code, int64_t n_code, uint8_t *out, int32_t
 int ofdm_sc_correlate_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frames, int64_t frame_stride,
                             int64_t frame_len, int64_t n_lags, int32_t *d_hat_dev, double *f_delta_dev,
                             float *metric_dev);
+/* xcorr_fft (src/signals/mod.rs:186-217) for every capture a[f] (a_len samples) against b (nb samples, device): the full
+ * cross-correlation out[i] = sum_n a[n + i - (a_len - 1)] conj(b[n]) over the 2 a_len - 1 fft_shifted indices (zero lag at
+ * a_len - 1), idx_max[f] = the FIRST index of the largest |out|^2 (0 when everything is zero, as the reference's loop), peak[f]
+ * (optional) = |out[idx_max]|, out_dev (optional, out_stride >= 2 a_len - 1) = the whole output.  Evaluated lag by lag in f64
+ * instead of through three odd-length FFTs: the same numbers to ~1e-15.  decode's offset is idx_max - a_len (receiver.rs:21). */
+int ofdm_xcorr_batch(ofdm_ctx *ctx, const ofdm_fc32 *a_dev, int64_t n_frames, int64_t a_stride, int64_t a_len,
+                     const ofdm_fc32 *b_dev, int32_t nb, int32_t *idx_max_dev, float *peak_dev, ofdm_fc32 *out_dev,
+                     int64_t out_stride);
 /* frequency_correction (src/receiver.rs:231-240): |mean_m angle(right[m]/left[m])| / L over n_pairs blocks of
  * L = n_fft+cp samples; pair p reads left = in[p*stride ..], right = in[p*stride + right_offset ..] */
 int ofdm_frequency_correction_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_pairs, int64_t stride,

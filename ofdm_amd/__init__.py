@@ -11,7 +11,7 @@ def __getattr__(name):
     # api imports torch and touches the GPU lazily; keep `import ofdm_amd` cheap
     if name in ("api", "Context", "encode", "decode", "channel", "default_pilots", "locking_signal", "preamble",
                 "training_signals", "OfdmError", "DecodeError", "BPSK", "QPSK", "QAM16", "QAM64", "QAM256",
-                "ECC_NONE", "ECC_HAMMING74", "CFO_OFF", "CFO_SIGNED", "CFO_ABS"):
+                "ECC_NONE", "ECC_HAMMING74", "CFO_OFF", "CFO_SIGNED", "CFO_ABS", "SYNC_SCHMIDL_COX", "SYNC_REFERENCE"):
         import importlib
 
         api = importlib.import_module(".api", __name__)

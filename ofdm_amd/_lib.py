@@ -17,7 +17,7 @@ class Params(C.Structure):
     _fields_ = [
         ("n_fft", C.c_int32), ("cp_len", C.c_int32), ("modulation", C.c_int32), ("guard_bands", C.c_int32),
         ("ecc", C.c_int32), ("sync_window_reps", C.c_int32), ("sync_backoff", C.c_int32), ("cfo_mode", C.c_int32),
-        ("sync_threshold", C.c_float), ("reserved", C.c_int32 * 7),
+        ("sync_threshold", C.c_float), ("sync_mode", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "ofdm_rx_demod_batch": (C.c_int, [vp, vp, i64, i64, i64, i32, i32, vp, vp, vp, i64, vp, i64, vp]),
     "ofdm_tx_encode_batch": (C.c_int, [vp, vp, i64, i64, vp, i32, vp, i64]),
     "ofdm_rx_decode_batch": (C.c_int, [vp, vp, i64, i64, i64, i64, i32, vp, i64, vp, vp, vp, vp, vp]),
+    "ofdm_xcorr_batch": (C.c_int, [vp, vp, i64, i64, i64, vp, i32, vp, vp, vp, i64]),
     "ofdm_channel_batch": (C.c_int, [vp, vp, i64, i64, i64, C.c_double, i32, C.c_uint64, vp, vp, vp, i64, i64, vp]),
     "ofdm_channel_taps": (C.c_int, [vp]),
     "ofdm_hbm_read_probe": (C.c_int, [vp, vp, i64, i32]),

@@ -20,7 +20,8 @@ from . import _lib
 BPSK, QPSK, QAM16, QAM64, QAM256 = 1, 2, 4, 6, 8  # ModulationScheme (src/transmitter.rs:98-104) as bits/point
 ECC_NONE, ECC_HAMMING74 = 0, 1
 CFO_OFF, CFO_SIGNED, CFO_ABS = 0, 1, 2
-FRAME_OK, FRAME_SHORT, FRAME_NOSYNC, FRAME_HEADER = 0, -1, -2, -4
+FRAME_OK, FRAME_SHORT, FRAME_NOSYNC, FRAME_BADTIMING, FRAME_HEADER = 0, -1, -2, -3, -4
+SYNC_SCHMIDL_COX, SYNC_REFERENCE = 0, 1
 
 
 class OfdmError(RuntimeError):
@@ -105,7 +106,8 @@ class Context:
     def __init__(self, n_fft: int = 64, modulation: int = BPSK, guard_bands: bool = False, ecc: int = ECC_NONE,
                  device: int = 0, preamble: Optional[np.ndarray] = None, training: Optional[np.ndarray] = None,
                  sync_window_reps: int = 3, sync_backoff: int = 4, cfo_mode: int = CFO_SIGNED,
-                 sync_threshold: float = 0.5, use_torch_stream: bool = True, pilots: str = "default"):
+                 sync_threshold: float = 0.5, use_torch_stream: bool = True, pilots: str = "default",
+                 sync_mode: int = SYNC_SCHMIDL_COX):
         self.lib = _lib.load()
         if pilots == "stdrng":  # the reference's own tables (restated, unverified) unless explicit tables are given
             sp, st = stdrng_pilots(n_fft)
@@ -121,6 +123,7 @@ class Context:
         p.n_fft, p.cp_len, p.modulation, p.guard_bands, p.ecc = n_fft, n_fft // 4, modulation, int(guard_bands), ecc
         p.sync_window_reps, p.sync_backoff, p.cfo_mode, p.sync_threshold = (sync_window_reps, sync_backoff, cfo_mode,
                                                                             sync_threshold)
+        p.sync_mode = sync_mode
         self.params = p
         pre = None if preamble is None else np.ascontiguousarray(preamble, dtype=np.complex128)
         trn = None if training is None else np.ascontiguousarray(training, dtype=np.complex128)
@@ -207,14 +210,15 @@ class Context:
         self._ck(self.lib.ofdm_ifft_cp_batch(self.h, _dev(freq), _dev(out), freq.numel() // self.n_fft), "ifft_cp")
         return out
 
-    def tx_symbols(self, data: torch.Tensor, n_sym: Optional[int] = None) -> torch.Tensor:
+    def tx_symbols(self, data: torch.Tensor, n_sym: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """modulate + encode_block + prefix_block fused (src/transmitter.rs:40-53): a continuous byte stream ->
         [n_sym, n_fft + cp] samples, identical to the three staged calls."""
         data = self._u8(data).reshape(-1)
         nb = data.numel()
         need = (nb + self.bytes_per_symbol - 1) // self.bytes_per_symbol
         n_sym = need if n_sym is None else n_sym
-        out = self.empty((n_sym, self.S), torch.complex64)
+        out = self.empty((n_sym, self.S), torch.complex64) if out is None else self._cx(out)
+        assert out.numel() == n_sym * self.S
         self._ck(self.lib.ofdm_tx_symbols_batch(self.h, _dev(data), nb, _dev(out), n_sym), "tx_symbols")
         return out
 
@@ -287,6 +291,20 @@ class Context:
         self._ck(self.lib.ofdm_sc_correlate_batch(self.h, _dev(f2), n, stride, frame_len, n_lags, _dev(d), _dev(fd),
                                                   _dev(m)), "sc_correlate")
         return d, fd, m
+
+    def xcorr(self, a: torch.Tensor, b: torch.Tensor, want_out: bool = False):
+        """SignalRef::xcorr_fft (src/signals/mod.rs:186-217) per row of a [n, len] against b [nb]: (idx_max i32, peak f32
+        [, the 2 len - 1 fft_shifted outputs])."""
+        a = self._cx(a)
+        a2 = a.view(-1, a.shape[-1])
+        b = self._cx(b).reshape(-1)
+        n, ln = a2.shape
+        idx = self.empty((n,), torch.int32)
+        pk = self.empty((n,), torch.float32)
+        out = self.empty((n, 2 * ln - 1), torch.complex64) if want_out else None
+        self._ck(self.lib.ofdm_xcorr_batch(self.h, _dev(a2), n, ln, ln, _dev(b), b.numel(), _dev(idx), _dev(pk), _dev(out),
+                                           2 * ln - 1), "xcorr")
+        return (idx, pk, out) if want_out else (idx, pk)
 
     def frequency_correction(self, left_right: torch.Tensor) -> torch.Tensor:
         """frequency_correction (src/receiver.rs:231-240): rows of [left(S) | right(S)] -> f64 |f_delta|."""
@@ -457,6 +475,7 @@ def decode(samples, guard_bands: Optional[bool] = None, modulation: Optional[int
     if status == FRAME_SHORT:
         raise DecodeError("Input not long enough, bailing early")
     if status != FRAME_OK:
-        raise DecodeError({FRAME_NOSYNC: "no preamble found", FRAME_HEADER: "no length header decoded"}.get(status, "decode failed"))
+        raise DecodeError({FRAME_NOSYNC: "no preamble found", FRAME_HEADER: "no length header decoded",
+                           FRAME_BADTIMING: "timing offset outside the capture (the reference panics in split_off)"}.get(status, "decode failed"))
     n = int(res["len"][0])
     return bytes(res["bytes"][0, :n].cpu().numpy())

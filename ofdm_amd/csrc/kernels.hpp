@@ -134,8 +134,17 @@ bool sc_big_ok(const ScParams &p);
 size_t sc_big_workspace_bytes(const ScParams &p);
 hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_t st);
 hipError_t run_sc_min_cross(const long long *cross, int tiles_per_frame, long long n_frames, int32_t *d1, hipStream_t st);
+// base (optional): per-pair sample offset added to the pair's start; status (optional): pairs with status != 0 get 0
 hipError_t run_freq_correction(const float2 *in, long long n_pairs, long long stride, long long right_offset, int L,
-                               double *f_delta, hipStream_t st);
+                               double *f_delta, hipStream_t st, const int32_t *base = nullptr, const int32_t *status = nullptr);
+// xcorr_fft (src/signals/mod.rs:186-217) of every capture a[f] (N samples) with b (nb samples): idx_max into the fft_shifted
+// 2N - 1 output, |.| at it, optionally the whole output
+size_t xcorr_workspace_bytes(long long n_frames, long long N, int nb);
+hipError_t run_xcorr(const float2 *a, long long n_frames, long long stride, long long N, const float2 *b, int nb, void *workspace,
+                     int32_t *idx_max, float *peak, float2 *out, long long out_stride, int num_cu, hipStream_t st);
+// reference timing -> trimmed offset (src/receiver.rs:21-36): offset = idx_max - N
+hipError_t run_rx_prepare_ref(long long n_frames, const int32_t *idx_max, long long frame_len, int L, int max_symbols,
+                              int bytes_per_symbol, int32_t *status, int32_t *offset, int32_t *nsym, hipStream_t st);
 hipError_t run_cfo_rotate(float2 *x, long long n_frames, long long frame_stride, long long frame_len,
                           const double *f_delta, const int32_t *first_index, hipStream_t st);
 

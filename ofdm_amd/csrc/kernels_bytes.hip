@@ -223,6 +223,37 @@ __global__ __launch_bounds__(256) void k_rx_prepare(long long n_frames, const in
     if (f < n_frames)
         rx_prepare_one(f, d_hat, f_delta, frame_len, L, backoff, cfo_mode, max_symbols, bytes_per_symbol, status, offset, nsym);
 }
+// reference timing (src/receiver.rs:21-36): offset = idx_max - ((2N - 1 - 1) / 2 + 1) = idx_max - N = lag - 1 (quirk Q1: a
+// zero-delay capture gives -1, where the reference panics in split_off -> OFDM_FRAME_BADTIMING)
+__global__ __launch_bounds__(256) void k_rx_prepare_ref(long long n_frames, const int32_t *idx_max, long long frame_len, int L,
+                                                        int max_symbols, int bytes_per_symbol, int32_t *status, int32_t *offset,
+                                                        int32_t *nsym) {
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_frames) return;
+    const long long off = (long long)idx_max[f] - frame_len;
+    int st = 0, ns = 0;
+    if (off < 0 || off > frame_len) st = -3;                   // Vec::split_off(offset as usize) out of range
+    else {
+        const long long len = frame_len - off;
+        if (len < 10LL * L) st = -1;                           // "Input not long enough, bailing early"
+        else {
+            const long long chunks = (len + L - 1) / L - 10;
+            ns = (int)(chunks < max_symbols ? chunks : max_symbols);
+            if ((long long)ns * bytes_per_symbol < 16) { st = -4; ns = 0; }
+        }
+    }
+    status[f] = st;
+    offset[f] = (int32_t)off;
+    nsym[f] = st == 0 ? ns : 0;
+}
+hipError_t run_rx_prepare_ref(long long n_frames, const int32_t *idx_max, long long frame_len, int L, int max_symbols,
+                              int bytes_per_symbol, int32_t *status, int32_t *offset, int32_t *nsym, hipStream_t st) {
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rx_prepare_ref, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, n_frames, idx_max, frame_len, L,
+                       max_symbols, bytes_per_symbol, status, offset, nsym);
+    return hipGetLastError();
+}
+
 hipError_t run_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_delta, long long frame_len, int L,
                           int backoff, int cfo_mode, int max_symbols, int bytes_per_symbol, int32_t *status,
                           int32_t *offset, int32_t *nsym, hipStream_t st, const int32_t *frame_list,

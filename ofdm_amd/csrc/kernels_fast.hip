@@ -670,11 +670,11 @@ __global__ __launch_bounds__(512) void k_demod4096(Big4096Params p) {
         bfly8<false>(v);
         // v[q] = Y_b[c = t + 8 q]; twiddle and transpose
 #pragma unroll
-        for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + col] = cmul(v[q], z[q]);
+        for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + (col ^ (t & 6))] = cmul(v[q], z[q]); // column XOR-swizzled by the row: conflict-free both ways
         __syncthreads(); // T complete; the image is clear
         // ---- stage B: FFT64 over b for row c = col
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = T[col * TS + t + 8 * m];
+        for (int m = 0; m < 8; ++m) v[m] = T[col * TS + (t ^ (col & 6)) + 8 * m]; // (t + 8 m) ^ s = (t ^ s) + 8 m for s < 8: offsets stay immediates
         bfly8<false>(v);
 #pragma unroll
         for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
@@ -1059,10 +1059,10 @@ __global__ __launch_bounds__(512) void k_tx4096(Tx4096Params p) {
         for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
         bfly8<true>(v);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + col] = cmul(v[q], z[q]);
+        for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + (col ^ (t & 6))] = cmul(v[q], z[q]); // column XOR-swizzled by the row: conflict-free both ways
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = T[col * TS + t + 8 * m];
+        for (int m = 0; m < 8; ++m) v[m] = T[col * TS + (t ^ (col & 6)) + 8 * m]; // (t + 8 m) ^ s = (t ^ s) + 8 m for s < 8: offsets stay immediates
         bfly8<true>(v);
 #pragma unroll
         for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
@@ -1079,14 +1079,14 @@ __global__ __launch_bounds__(512) void k_tx4096(Tx4096Params p) {
         // store is a full 16 bytes per lane and 1 KiB per wavefront
         __syncthreads(); // every wavefront has read its stage-B inputs out of T
 #pragma unroll
-        for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + col] = make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N));
+        for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + (col ^ (t & 6))] = make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N));
         __syncthreads();
         {
             float4 *dst4 = reinterpret_cast<float4 *>(p.out + sg * S);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = tid + 512 * j, n = 2 * i;                      // sample pair (n, n + 1)
-                const float4 y = *reinterpret_cast<const float4 *>(T + (n >> 6) * TS + (n & 63));
+                const float4 y = *reinterpret_cast<const float4 *>(T + (n >> 6) * TS + ((n & 63) ^ ((n >> 6) & 6))); // an even XOR keeps the pair adjacent
                 dst4[(CP >> 1) + i] = y;
                 if (j == 3) dst4[i - ((N - CP) >> 1)] = y;                   // n >= N - CP: the cyclic prefix
             }

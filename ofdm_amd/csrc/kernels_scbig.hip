@@ -45,22 +45,32 @@ __device__ __forceinline__ BCand bc_shfl_xor(BCand a, int d) {
                  __shfl_xor(a.lag, d, 64)};
 }
 
-// coalesced staging of `count` samples starting at sample `first` of a frame into LDS, zero past the capture
-__device__ __forceinline__ void stage_segment(cf *dst, const cf *frame, long long first, int count, long long frame_len, int tid, int nthr) {
-    const cf *src = frame + first;
-    const long long avail = frame_len - first; // may be <= 0
-    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-        const float4 *s4 = reinterpret_cast<const float4 *>(src);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int i = tid; i < count / 2; i += nthr) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (2 * i + 1 < avail) x = s4[i];
-            else if (2 * i < avail) { const cf y = src[2 * i]; x.x = y.x; x.y = y.y; }
-            d4[i] = x;
+// Coalesced staging of NSEG segments of PER * nthr * 2 samples each into LDS, zero past the capture.  All loads of all
+// segments are issued before the first LDS store (a load -> store -> load chain would expose the memory latency once per
+// 16 bytes: measured 20 us per 40 KB tile).
+template <int NSEG, int PER>
+__device__ __forceinline__ void stage_segments(cf *const *dst, const cf *frame, const long long *first, long long frame_len, int tid, int nthr) {
+    float4 x[NSEG][PER];
+#pragma unroll
+    for (int g = 0; g < NSEG; ++g) {
+        const cf *src = frame + first[g];
+        const long long avail = frame_len - first[g]; // may be <= 0
+        const bool al = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + j * nthr;             // float4 index inside the segment
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (2 * i + 1 < avail) {
+                if (al) v = reinterpret_cast<const float4 *>(src)[i];
+                else { const cf a = src[2 * i], b = src[2 * i + 1]; v = make_float4(a.x, a.y, b.x, b.y); }
+            } else if (2 * i < avail) { const cf a = src[2 * i]; v.x = a.x; v.y = a.y; }
+            x[g][j] = v;
         }
-    } else {
-        for (int i = tid; i < count; i += nthr) dst[i] = i < avail ? src[i] : make_float2(0.f, 0.f);
     }
+#pragma unroll
+    for (int g = 0; g < NSEG; ++g)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) reinterpret_cast<float4 *>(dst[g])[tid + j * nthr] = x[g][j];
 }
 
 } // namespace
@@ -78,8 +88,11 @@ __global__ __launch_bounds__(256) void k_scb_chunks(ScBigParams p) {
         const cf *frame = p.in + f * p.frame_stride;
         const long long t0 = (long long)tile * B_TILE;
         __syncthreads(); // the previous item's readers are done
-        stage_segment(seg_a, frame, t0, B_TILE, p.frame_len, tid, 256);
-        stage_segment(seg_b, frame, t0 + p.L, B_TILE, p.frame_len, tid, 256);
+        {
+            cf *const dsts[2] = {seg_a, seg_b};
+            const long long firsts[2] = {t0, t0 + p.L};
+            stage_segments<2, B_TILE / 2 / 256>(dsts, frame, firsts, p.frame_len, tid, 256);
+        }
         __syncthreads();
         double qr = 0.0, qi = 0.0, e = 0.0;
         {
@@ -169,10 +182,11 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
         // first maximum over [max(lo, crossing), hi].  Returns the crossing (INT_MAX: none) through *cross_out.
         auto eval_tile = [&](long long d0, long long lo, long long hi, bool want_cross, long long &cross_out, BCand &best) {
             __syncthreads();
-            stage_segment(s0, frame, d0, F_TILE + 16, p.frame_len, tid, F_WG);
-            stage_segment(s1, frame, d0 + L, F_TILE + 16, p.frame_len, tid, F_WG);
-            stage_segment(s2, frame, d0 + W, F_TILE + 16, p.frame_len, tid, F_WG);
-            stage_segment(s3, frame, d0 + W + L, F_TILE + 16, p.frame_len, tid, F_WG);
+            {
+                cf *const dsts[4] = {s0, s1, s2, s3};
+                const long long firsts[4] = {d0, d0 + L, d0 + W, d0 + W + L};
+                stage_segments<4, F_TILE / 2 / F_WG>(dsts, frame, firsts, p.frame_len, tid, F_WG);
+            }
             __syncthreads();
             const int a0 = tid * 10;
             BSums pre[10];
@@ -326,7 +340,7 @@ hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_
     q.ws = reinterpret_cast<double *>(workspace);
     q.d_hat = p.d_hat; q.f_delta = p.f_delta; q.metric = p.metric;
     const long long items = p.n_frames * (long long)q.tiles_per_frame;
-    long long g1 = (long long)num_cu * 3; // 40 KB of LDS per workgroup
+    long long g1 = (long long)num_cu * 4; // 40 KB of LDS per workgroup
     if (g1 > items) g1 = items;
     hipLaunchKernelGGL(k_scb_chunks, dim3((unsigned)g1), dim3(256), 0, st, q);
     hipError_t e = hipGetLastError();

@@ -1016,13 +1016,120 @@ hipError_t run_sc_min_cross(const long long *cross, int tiles, long long n_frame
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// xcorr_fft (src/signals/mod.rs:186-217): the reference's timing detector -- full cross-correlation of a capture a (N samples)
+// with a short signal b (the 80-sample locking ramp in decode, src/receiver.rs:20), zero-padded to 2N - 1, fft_shifted, and
+// the FIRST index of the largest |.|^2 (strictly greater replaces; start value 0).  In exact arithmetic
+//     out[i] = c[i - (N - 1)],   c[k] = sum_n a[n + k] conj(b[n])      (zero lag at index N - 1; a = 0 outside [0, N))
+// and c[k] = 0 for k < -(nb - 1): those indices can never win.  The reference evaluates this with three FFTs of the odd length
+// 2N - 1; here every lag is the direct nb-term sum, accumulated in f64 (products of f32 samples are exact in f64), which
+// is the same number to ~1e-15 and needs no odd-length transform: one workgroup per (frame, tile of 2048 lags), the tile's
+// 2048 + nb samples and b staged in LDS, 8 lags per thread, taps consumed 8 at a time from a 15-sample register window.
+struct XcorrBest { double val; long long idx; };
+__global__ __launch_bounds__(256) void k_xcorr(const cf *a, long long n_frames, long long stride, long long N, const cf *b, int nb,
+                                               int tiles, XcorrBest *tile_best, cf *out, long long out_stride) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int nbp = (nb + 7) / 8 * 8;                 // taps padded with zeros to a multiple of 8
+    cf *sa = reinterpret_cast<cf *>(smem);            // [2048 + nbp + 8]
+    cf *sb = sa + 2048 + nbp + 8;                     // [nbp]
+    __shared__ XcorrBest wbest[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long items = n_frames * (long long)tiles;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const long long f = it / tiles;
+        const int tile = (int)(it - f * tiles);
+        const cf *af = a + f * stride;
+        const long long k0 = -(long long)(nb - 1) + (long long)tile * 2048; // first lag of the tile
+        __syncthreads();
+        for (int i = tid; i < 2048 + nbp + 8; i += 256) { const long long j = k0 + i; sa[i] = (j >= 0 && j < N) ? af[j] : make_float2(0.f, 0.f); }
+        for (int i = tid; i < nbp; i += 256) sb[i] = i < nb ? b[i] : make_float2(0.f, 0.f);
+        __syncthreads();
+        const int l0 = tid * 8;
+        double cr[8], ci[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cr[j] = 0.0; ci[j] = 0.0; }
+        for (int n0 = 0; n0 < nbp; n0 += 8) {
+            double wr[15], wi[15];
+#pragma unroll
+            for (int j = 0; j < 15; ++j) { const cf v = sa[l0 + n0 + j]; wr[j] = v.x; wi[j] = v.y; }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const cf t = sb[n0 + n];
+                const double br = t.x, bi = t.y; // a * conj(b) = (ar br + ai bi) + j (ai br - ar bi)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { cr[j] += wr[j + n] * br + wi[j + n] * bi; ci[j] += wi[j + n] * br - wr[j + n] * bi; }
+            }
+        }
+        XcorrBest mine = XcorrBest{0.0, LLONG_MAX};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long k = k0 + l0 + j;         // lag; output index i = k + N - 1
+            if (k <= N - 1) {
+                const double v = cr[j] * cr[j] + ci[j] * ci[j];
+                if (v > mine.val) mine = XcorrBest{v, k + N - 1};
+                if (out) out[f * out_stride + (k + N - 1)] = make_float2((float)cr[j], (float)ci[j]);
+            }
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const double ov = __shfl_xor(mine.val, sft, 64);
+            const long long oi = __shfl_xor(mine.idx, sft, 64);
+            if (ov > mine.val || (ov == mine.val && oi < mine.idx)) mine = XcorrBest{ov, oi};
+        }
+        if (lane == 0) wbest[wave] = mine;
+        __syncthreads();
+        if (tid == 0) {
+            XcorrBest m = wbest[0];
+            for (int wv = 1; wv < 4; ++wv) if (wbest[wv].val > m.val || (wbest[wv].val == m.val && wbest[wv].idx < m.idx)) m = wbest[wv];
+            tile_best[it] = m;
+        }
+        if (out && tile == 0) // indices below N - nb are exact zeros of the correlation
+            for (long long i = tid; i < N - nb; i += 256) out[f * out_stride + i] = make_float2(0.f, 0.f);
+    }
+}
+__global__ __launch_bounds__(256) void k_xcorr_pick(const XcorrBest *tile_best, long long n_frames, int tiles, int32_t *idx_max, float *peak) {
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_frames) return;
+    XcorrBest m = XcorrBest{0.0, 0}; // `max = Complex64::default(); idx_max = 0` (signals/mod.rs:206-207)
+    for (int t = 0; t < tiles; ++t) { const XcorrBest c = tile_best[f * tiles + t]; if (c.val > m.val) m = c; } // ascending lags: first maximum wins
+    idx_max[f] = (int32_t)m.idx;
+    if (peak) peak[f] = (float)sqrt(m.val);
+}
+size_t xcorr_workspace_bytes(long long n_frames, long long N, int nb) {
+    const long long tiles = (N + nb - 1 + 2047) / 2048;
+    return (size_t)(n_frames * tiles) * sizeof(XcorrBest);
+}
+hipError_t run_xcorr(const float2 *a, long long n_frames, long long stride, long long N, const float2 *b, int nb, void *workspace,
+                     int32_t *idx_max, float *peak, float2 *out, long long out_stride, int num_cu, hipStream_t st) {
+    if (n_frames <= 0) return hipSuccess;
+    const long long tiles = (N + nb - 1 + 2047) / 2048; // lags -(nb - 1) .. N - 1
+    if (tiles > 0x7fffffff) return hipErrorInvalidValue;
+    const int nbp = (nb + 7) / 8 * 8;
+    const size_t lds = (size_t)(2048 + 2 * nbp + 8) * sizeof(float2);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_xcorr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    long long grid = (long long)num_cu * 4, items = n_frames * tiles;
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(k_xcorr, dim3((unsigned)grid), dim3(256), lds, st, a, n_frames, stride, N, b, nb, (int)tiles,
+                       reinterpret_cast<XcorrBest *>(workspace), out, out_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_xcorr_pick, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const XcorrBest *>(workspace), n_frames, (int)tiles, idx_max, peak);
+    return hipGetLastError();
+}
+
 // frequency_correction (src/receiver.rs:231-240): one wavefront per (left, right) pair
 __global__ __launch_bounds__(256) void k_freq_corr(const cf *in, long long n_pairs, long long stride,
-                                                   long long right_offset, int L, double *f_delta) {
+                                                   long long right_offset, int L, double *f_delta, const int32_t *base,
+                                                   const int32_t *status) {
     const int lane = threadIdx.x & 63;
     long long pidx = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pidx >= n_pairs) return;
-    const cf *l = in + pidx * stride, *r = l + right_offset;
+    if (status && status[pidx] != 0) { if (lane == 0) f_delta[pidx] = 0.0; return; } // no valid block pair in this capture
+    const cf *l = in + pidx * stride + (base ? base[pidx] : 0), *r = l + right_offset;
     double sum = 0.0;
     for (int m = lane; m < L; m += 64) {    // all f64 like the reference (receiver.rs:231-240): products of f32 are exact
         const double lr = l[m].x, li = l[m].y, rr = r[m].x, ri = r[m].y;
@@ -1034,10 +1141,10 @@ __global__ __launch_bounds__(256) void k_freq_corr(const cf *in, long long n_pai
     if (lane == 0) f_delta[pidx] = fabs((sum / (double)L) / (double)L);
 }
 hipError_t run_freq_correction(const float2 *in, long long n_pairs, long long stride, long long right_offset, int L,
-                               double *f_delta, hipStream_t st) {
+                               double *f_delta, hipStream_t st, const int32_t *base, const int32_t *status) {
     if (n_pairs <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_freq_corr, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, st, in, n_pairs, stride,
-                       right_offset, L, f_delta);
+                       right_offset, L, f_delta, base, status);
     return hipGetLastError();
 }
 

@@ -306,6 +306,7 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
     if (p->sync_backoff < 0 || p->sync_backoff > p->cp_len) return OFDM_ERR_INVALID;
     if (p->cfo_mode < OFDM_CFO_OFF || p->cfo_mode > OFDM_CFO_ABS) return OFDM_ERR_INVALID;
     if (!(p->sync_threshold > 0.f && p->sync_threshold <= 1.f)) return OFDM_ERR_INVALID;
+    if (p->sync_mode != OFDM_SYNC_SCHMIDL_COX && p->sync_mode != OFDM_SYNC_REFERENCE) return OFDM_ERR_INVALID;
     for (int r : p->reserved) if (r != 0) return OFDM_ERR_INVALID;
 
     int ndev = 0;
@@ -569,7 +570,8 @@ static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame
     }
     // long periods (N >= 128): one streaming pass for chunk sums, then an exact search only where the chunk bounds allow a
     // crossing / a new maximum (kernels_scbig.hip); LDS footprint independent of L, so N = 4096 works too
-    if (sc_big_ok(p) && getenv("OFDM_NO_SC_BIG") == nullptr) {
+    const bool one_small_tile = n_lags <= sc_tile_lags() && sc_lds_bytes(p) <= 64 * 1024; // bounded search, window in LDS: k_sc_tile reads less
+    if (sc_big_ok(p) && !one_small_tile && getenv("OFDM_NO_SC_BIG") == nullptr) {
         void *wsp;
         int rc = ws_get(c, 6, sc_big_workspace_bytes(p), &wsp);
         if (rc) return rc;
@@ -606,6 +608,22 @@ int ofdm_sc_correlate_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, 
     DeviceGuard dev_guard(c->device);
     return sc_run(c, reinterpret_cast<const float2 *>(in), n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric);
 }
+int ofdm_xcorr_batch(ofdm_ctx *c, const ofdm_fc32 *a, int64_t n_frames, int64_t a_stride, int64_t a_len, const ofdm_fc32 *b,
+                     int32_t nb, int32_t *idx_max, float *peak, ofdm_fc32 *out, int64_t out_stride) {
+    if (!c || n_frames < 0 || a_len <= 0 || nb <= 0 || nb > 8192 || nb > a_len || a_len > 0x3fffffff) return OFDM_ERR_INVALID;
+    if (n_frames && (!a || !b || !idx_max)) return OFDM_ERR_INVALID;
+    if (n_frames > 1 && a_stride <= 0) return OFDM_ERR_INVALID;
+    if (out && out_stride < 2 * a_len - 1) return OFDM_ERR_INVALID;
+    if (!n_frames) return OFDM_OK;
+    DeviceGuard dev_guard(c->device);
+    void *w;
+    int rc = ws_get(c, 6, xcorr_workspace_bytes(n_frames, a_len, nb), &w);
+    if (rc) return rc;
+    HIP_TRY(c, run_xcorr(reinterpret_cast<const float2 *>(a), n_frames, a_stride, a_len, reinterpret_cast<const float2 *>(b), nb, w,
+                         idx_max, peak, reinterpret_cast<float2 *>(out), out_stride, c->num_cu, c->stream));
+    return OFDM_OK;
+}
+
 int ofdm_frequency_correction_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_pairs, int64_t stride,
                                     int64_t right_offset, double *f_delta) {
     if (!c || n_pairs < 0 || (n_pairs && (!in || !f_delta))) return OFDM_ERR_INVALID;
@@ -741,7 +759,7 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     // 0. N = 64 frames that fit one LDS tile: timing, CFO, channel estimate, demod and the finish in ONE kernel and one
     //    pass over HBM (k_sc_cf<..., BPS>, kernels_sync.hip).  The few frames its f32 filter cannot settle come back on
     //    a device-side list and take the list-mode kernels below.
-    if (N == 64) {
+    if (N == 64 && c->prm.sync_mode == OFDM_SYNC_SCHMIDL_COX) {
         // Opt-in (OFDM_ONE_PASS_RX=1, read per call: the parity tests flip it): measured on MI355X the one-pass kernel moves
         // half the HBM bytes of the staged chain but is VALU-issue bound with 12 wavefronts per CU (its LDS footprint), 2.2 ms
         // against 1.95 ms per 262 144 config-3 frames; see DESIGN.md section 5.2.
@@ -776,12 +794,26 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         }
     }
     if ((rc = ws_get(c, 5, (size_t)raw_stride * (size_t)n_frames, &w_raw))) return rc;
+    if (c->prm.sync_mode == OFDM_SYNC_REFERENCE) {
+        // 1r. the reference's own detector (src/receiver.rs:20-25): cross-correlation with the locking signal, offset =
+        //     idx_max - N (= lag - 1), then frequency_correction on chunks 3 and 4 (receiver.rs:39; always |.|)
+        if (frame_len > 0x3fffffff) return OFDM_ERR_UNSUPPORTED;
+        void *w_x;
+        if ((rc = ws_get(c, 6, xcorr_workspace_bytes(n_frames, frame_len, c->S()), &w_x))) return rc;
+        HIP_TRY(c, run_xcorr(x, n_frames, frame_stride, frame_len, c->d_header, c->S(), w_x, (int32_t *)w_dhat, metric, nullptr, 0,
+                             c->num_cu, c->stream));
+        HIP_TRY(c, run_rx_prepare_ref(n_frames, (const int32_t *)w_dhat, frame_len, c->S(), max_symbols, bps_bytes, status, offs,
+                                      (int32_t *)w_nsym, c->stream));
+        if (c->prm.cfo_mode == OFDM_CFO_OFF) HIP_TRY(c, hipMemsetAsync(fd, 0, sizeof(double) * (size_t)n_frames, c->stream));
+        else HIP_TRY(c, run_freq_correction(x + 3 * c->S(), n_frames, frame_stride, c->S(), c->S(), fd, c->stream, offs, status));
+    } else {
     // 1. timing + CFO: Schmidl-Cox over the repeated preamble (replaces xcorr_fft, src/receiver.rs:20-25,39)
     rc = sc_run(c, x, n_frames, frame_stride, frame_len, n_lags, (int32_t *)w_dhat, fd, metric);
     if (rc) return rc;
     // 2. trimmed start, length check, live symbols (receiver.rs:21-36)
     HIP_TRY(c, run_rx_prepare(n_frames, (const int32_t *)w_dhat, fd, frame_len, c->S(), c->prm.sync_backoff,
                               c->prm.cfo_mode, max_symbols, bps_bytes, status, offs, (int32_t *)w_nsym, c->stream));
+    }
     // 3+4. channel estimate from the 5 training blocks and per data symbol CP strip + FFT + equalise + pilot phase +
     //      demap (receiver.rs:44-83).  N = 64: one fused wave-centric kernel; otherwise the generic pair.
     bool fused = false, finished = false;

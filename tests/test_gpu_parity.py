@@ -702,6 +702,93 @@ def test_bounded_search_clips_the_peak_window(api, orc):
     assert res["status"][0] == w["status"] and res["offset"][0] == w["offset"]
 
 
+# ------------------------------------------------------------------ a11 / a12: the reference's own timing (xcorr_fft, offset = lag - 1)
+def test_xcorr_reference_kats_and_oracle(api, orc):
+    """ofdm_xcorr_batch = SignalRef::xcorr_fft (src/signals/mod.rs:186-217) on the GPU: the reference's two known answers
+    (signals/mod.rs:420-441: [1,2,3] x [4,5] -> [0,5,14,23,12], idx_max 3; the 8 / 4 sample pair -> idx_max 7), and
+    against the oracle's FFT-based restatement on a capture with the locking signal (the decode use): idx_max exact,
+    outputs <= 1e-5."""
+    import json, os
+    ctx = api.Context()
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))["xcorr"]
+    for case in kat:
+        a = np.asarray(case["a"], np.complex64); b = np.asarray(case["b"], np.complex64)
+        idx, pk, out = ctx.xcorr(dev(ctx, a.reshape(1, -1)), dev(ctx, b), want_out=True)
+        assert int(host(idx)[0]) == case["idx_max"]
+        np.testing.assert_allclose(host(out)[0].real, case["full"], atol=1e-5)
+    a = np.array([1, 2, 3], np.complex64); b = np.array([4, 5], np.complex64)
+    idx, pk, out = ctx.xcorr(dev(ctx, a.reshape(1, -1)), dev(ctx, b), want_out=True)
+    np.testing.assert_allclose(host(out)[0], [0, 5, 14, 23, 12], atol=1e-6)
+    assert int(host(idx)[0]) == 3 and abs(float(host(pk)[0]) - 23.0) < 1e-5
+    a = np.array([1, 1, 0, 0, 1, 1, 0, 0], np.complex64); b = np.array([1, 1, 0, 0], np.complex64)
+    idx, pk, out = ctx.xcorr(dev(ctx, a.reshape(1, -1)), dev(ctx, b), want_out=True)
+    np.testing.assert_allclose(host(out)[0], [0, 0, 0, 0, 0, 0, 1, 2, 1, 0, 1, 2, 1, 0, 0], atol=1e-6)
+    assert int(host(idx)[0]) == 7
+    # against the oracle on captures (complex b, several tiles of lags, a batch)
+    rng = np.random.default_rng(11)
+    lock = fc32(orc.locking_signal(80))
+    caps = []
+    for f in range(4):
+        tx = orc.encode(bytes(rng.integers(0, 256, 600, dtype=np.uint8)), True, orc.QAM64)
+        caps.append(through_channel(orc, rng, tx, 5000, int(rng.integers(1, 300)), 0.003 * f, 25.0, data_start=800))
+    caps = np.stack(caps)
+    idx, pk, out = ctx.xcorr(dev(ctx, caps), dev(ctx, lock), want_out=True)
+    bz = fc32(rng.standard_normal(37) + 1j * rng.standard_normal(37))
+    idx2, pk2, out2 = ctx.xcorr(dev(ctx, caps), dev(ctx, bz), want_out=True)
+    for f in range(4):
+        wi, wout = orc.xcorr_fft(wide(caps[f]), wide(lock))
+        assert int(host(idx)[f]) == wi and rel_err(host(out)[f], wout) <= TOL
+        assert abs(float(host(pk)[f]) - abs(wout[wi])) <= 1e-5 * abs(wout[wi])
+        wi, wout = orc.xcorr_fft(wide(caps[f]), wide(bz))
+        assert int(host(idx2)[f]) == wi and rel_err(host(out2)[f], wout) <= TOL
+    z = ctx.xcorr(dev(ctx, np.zeros((1, 100), np.complex64)), dev(ctx, lock))
+    assert int(host(z[0])[0]) == 0 and float(host(z[1])[0]) == 0.0      # nothing exceeds the start value 0: idx_max stays 0
+
+
+@pytest.mark.parametrize("n,mod,guard,nbytes", [(64, 2, False, 400), (64, 6, True, 560), (1024, 4, True, 1500)])
+def test_rx_decode_reference_sync_mode(api, orc, n, mod, guard, nbytes):
+    """decode with the reference's own detector pair (OFDM_SYNC_REFERENCE: xcorr_fft timing, offset = lag - 1, quirk Q1;
+    frequency_correction CFO with its abs(), quirk Q2) against the oracle's decode_ref (src/receiver.rs:9-96 as written):
+    status, offset, CFO (1e-9) and bytes, including the zero-delay capture the reference panics on (offset -1)."""
+    rng = np.random.default_rng(12 + n + mod)
+    S = n + n // 4
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard, sync_mode=api.SYNC_REFERENCE, cfo_mode=api.CFO_ABS)
+    D = ctx.data_symbols(nbytes)
+    flen = ctx.frame_samples(nbytes)
+    span = flen + 2 * S
+    caps = []
+    for f in range(6):
+        tx = orc.encode(bytes(rng.integers(0, 256, nbytes, dtype=np.uint8)), guard, mod, n)
+        d = int(rng.integers(2, S))
+        fd = rng.random() * 0.5 * np.pi / S
+        caps.append(through_channel(orc, rng, tx, span, d, fd, 33.0, data_start=10 * S))
+    tx = orc.encode(bytes(rng.integers(0, 256, nbytes, dtype=np.uint8)), guard, mod, n)
+    z = np.zeros(span, np.complex64); z[: tx.size] = fc32(tx)          # zero delay, no channel: lag 0 -> offset -1
+    caps.append(z)
+    caps.append(caps[0][: span].copy()); caps[-1][9 * S:] = 0            # too short after trimming
+    caps = np.stack(caps)
+    res = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=D + 2).items()}
+    n_ok = 0
+    for f in range(caps.shape[0]):
+        w = orc.decode_ref(wide(caps[f]), guard, mod, n, want_soft=True)
+        assert res["status"][f] == w["status"], (f, res["status"][f], w["status"])
+        assert res["offset"][f] == w["offset"], f
+        if w["status"] != 0:
+            assert res["len"][f] == 0
+            continue
+        n_ok += 1
+        assert abs(res["f_delta"][f] - w["f_delta"]) <= 1e-9
+        got = bytes(res["bytes"][f][: res["len"][f]])
+        if got != w["bytes"]:
+            assert len(got) == len(w["bytes"])
+            gb = np.unpackbits(np.frombuffer(got, np.uint8), bitorder="little")
+            wb = np.unpackbits(np.frombuffer(w["bytes"], np.uint8), bitorder="little")
+            pts = np.unique((128 + np.nonzero(gb != wb)[0]) // mod)
+            from util import decision_margin
+            assert np.all(decision_margin(np.asarray(w["soft"])[pts], mod) < TOL), f
+    assert n_ok >= 5 and res["status"][6] == -3 and res["offset"][6] == -1
+
+
 # ------------------------------------------------------------------ a24: channel (src/channel.rs:33-74) on the GPU
 def test_channel_batch_matches_the_oracle(api, orc):
     """ofdm_channel_batch against orc_channel with the same SplitMix64 streams: FIR CHANNEL, CFO exp(+j f (i+1)) with
