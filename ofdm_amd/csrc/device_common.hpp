@@ -184,11 +184,26 @@ __device__ __forceinline__ cf cfo_phasor(double turns, long long n) {
 // returns the bps-bit index: bit j = j-th bit of the point in stream order
 __device__ __forceinline__ unsigned axis_bits(float x, int m) {
     const int M = 1 << m;
-    float u = x * (float)(M - 1);
-    float f = floorf(u * 0.5f) + (float)(M / 2);
-    f = fminf(fmaxf(f, 0.0f), (float)(M - 1)); // NaN -> 0 (fmaxf returns the non-NaN operand)
-    unsigned l = (unsigned)f;
-    unsigned g = l ^ (l >> 1);                 // Gray code, MSB = first stream bit
+    // l = clamp(floor(x (M-1) / 2) + M/2, 0, M-1): one fma, clamp, truncating convert (the clamped value is non-negative, so
+    // truncation is the floor; NaN -> 0 because fmaxf returns the non-NaN operand)
+    float f = fmaf(x, 0.5f * (float)(M - 1), (float)(M / 2));
+    f = fminf(fmaxf(f, 0.0f), (float)(M - 1));
+    const unsigned l = (unsigned)f;
+    if (m <= 3) {
+        // Gray code + bit reversal (first stream bit at bit 0) from a compile-time table, m bits per entry: 2 instructions
+        // (shift-add, bit-field extract) instead of shift / xor / brev / shift
+        unsigned lut = 0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const unsigned g = (unsigned)i ^ ((unsigned)i >> 1);
+            unsigned r = 0;
+#pragma unroll
+            for (int b = 0; b < m; ++b) r |= ((g >> b) & 1u) << (m - 1 - b);
+            lut |= r << (m * i);
+        }
+        return __builtin_amdgcn_ubfe(lut, l * (unsigned)m, (unsigned)m);
+    }
+    const unsigned g = l ^ (l >> 1);           // Gray code, MSB = first stream bit
     return __brev(g) >> (32 - m);              // first stream bit at bit 0
 }
 __device__ __forceinline__ unsigned demap_point(cf z, int bps) {

@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
         for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            if (bitoff[m] >= 0) {
+            // bins t + 8 m with m in {1, 2, 5, 6} are data carriers for every lane (the nulls and pilots sit in rows 0, 3, 4, 7):
+            // no per-lane test, no exec-mask juggling for half of the fields
+            const bool all_data = !GUARD || m == 1 || m == 2 || m == 5 || m == 6;
+            if (all_data || bitoff[m] >= 0) {
                 const unsigned idx = demap_point(v[m], BPS);
                 const int wd = bitoff[m] >> 5, sh = bitoff[m] & 31;
                 atomicOr(&img[wd], idx << sh);
@@ -152,6 +155,8 @@ __global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
 //   (receiver.rs:99-104), equalise (receiver.rs:68-70), pilot phase (receiver.rs:106-145), hard demap + LSB-first packing
 //   (receiver.rs:147-190).  Frames may start at any sample offset (8-byte aligned loads), samples at or beyond
 //   frame_len read as zero (pad_chunk).  No workgroup barrier: the 4 waves of a workgroup own 4 different frames.
+//   (Round 2 measured a variant with the next group's / next frame's samples prefetched into registers: 242 VGPRs, two
+//   waves per SIMD, 1.12 ms per 262 144 config-3 frames against 0.94-1.14 ms for this one: no gain, not kept.)
 struct RxFrame64Params {
     const float2 *in;
     long long n_frames, frame_stride, frame_len;
@@ -596,7 +601,7 @@ struct Big4096Params {
 };
 
 template <int BPS, bool GUARD>
-__global__ __launch_bounds__(512) void k_demod4096(Big4096Params p) {
+__global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 waves per SIMD = two workgroups per CU: never more than 128 VGPRs
     constexpr int N = 4096, S = 5120, CP = 1024, TS = 72, SLAB = 8 * 72;
     constexpr int ND = GUARD ? 48 * 64 : N;
     constexpr int IMG_DW = ND * BPS / 32;                        // packed bytes of one symbol, in dwords (<= 1024)
@@ -981,7 +986,7 @@ struct Tx4096Params {
 };
 
 template <bool GUARD>
-__global__ __launch_bounds__(512) void k_tx4096(Tx4096Params p) {
+__global__ __launch_bounds__(512, 4) void k_tx4096(Tx4096Params p) {
     constexpr int N = 4096, S = 5120, CP = 1024, TS = 72, SLAB = 8 * 72;
     extern __shared__ __align__(16) unsigned char smem[];
     cf *slab_all = reinterpret_cast<cf *>(smem);
