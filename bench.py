@@ -257,9 +257,9 @@ def main():
     value = n_gpus * samples_per_step * a.steps / dt / 1e6
     kern_s = ev_ms / 1e3 / a.steps
     alg_bytes = F * (syms * ctx.S * 8 + syms * ctx.bytes_per_symbol)  # 8 B/sample read + packed bytes written
-    traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), scaled to F
+    traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/r02_pmc_traffic.json), scaled to F
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["k_demod64"]
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["k_demod64"]
         traffic = F * (pm["read_bytes_per_frame"] + pm["write_bytes_per_frame"])
     except Exception:
         pass
