@@ -56,6 +56,8 @@ struct Fast64Params {
     long long n_groups = 0, stride_groups = 0;
     long long f0 = 0, blk_df = 0, wave_df = 0, step_df = 0; // frame index bookkeeping without division
     int k0 = 0, blk_dk = 0, wave_dk = 0, step_dk = 0;
+    int wide_stores = 0;        // the packed image leaves with 16-byte stores (aligned output)
+    int debug = 0;              // profiling aid (OFDM_DEMOD64_DEBUG): 1 no stores, 2 no packing either, 3 loads + first butterfly only
 };
 hipError_t run_demod64_fast(const SymParams &p, hipStream_t st, int num_cu);
 // N = 4096 RX demod as 64 x 64 (regular streams: no offset / CFO / per-frame symbol counts / soft output)

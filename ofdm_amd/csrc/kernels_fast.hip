@@ -36,15 +36,25 @@ __device__ __forceinline__ float sum8(float x) {
     return x;
 }
 
-template <int BPS, bool GUARD, bool HK>
-__global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x2 *lds_cf_ptr; // LDS pointer built from a 32-bit offset held in a VGPR
+typedef __attribute__((address_space(3))) unsigned *lds_u32_ptr;
+__device__ __forceinline__ unsigned lds_offset(const void *p) {
+    return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char *)p);
+}
+// A per-lane constant the compiler must KEEP in a register: without the empty asm it rematerialises the XOR / shift / mask
+// that produced it inside the loop (to stay under 96 VGPRs), once per use and iteration.
+__device__ __forceinline__ unsigned pinned(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+
+template <int BPS, bool GUARD, bool HK, bool PF = false>
+__global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
     constexpr int N = 64, S = 80, CP = 16;
     constexpr int ND = GUARD ? 48 : 64;          // data carriers per symbol
     constexpr int REGION_DW = ND * BPS / 4;      // packed output of 8 symbols, in dwords
     constexpr int SLAB = 8 * 72;                 // 8 symbols x (64 + 8 pad) points
 
     __shared__ cf slab_all[4 * SLAB];
-    __shared__ unsigned img_all[4 * REGION_DW];
+    __shared__ __align__(16) unsigned img_all[4 * REGION_DW];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -65,14 +75,21 @@ __global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
             g[m] = make_float2(h.x / ns, -h.y / ns);
         }
     }
-    int bitoff[8]; // bit offset of bin (t + 8m)'s field inside the wave's packed image, -1 = not a data bin
+    // LDS byte addresses of the transpose (write: swz(8t + r) = 8t + (r ^ t); read: swz(t + 8m) = 8m + (t ^ m)) and of every
+    // field's dword in the packed image, with the field's shift: 8 + 8 + 8 + 8 registers instead of ~5 integer instructions
+    // per access and iteration (the kernel runs at 4 waves per SIMD either way: measured insensitive between 4 and 5)
+    unsigned wa[8], ra[8], fa[8], fs[8]; // fs: bit shift inside the dword, 0xFFFFFFFF = not a data bin
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int c = t + 8 * m;
+    for (int r = 0; r < 8; ++r) {
+        wa[r] = pinned(lds_offset(buf + (swz(8 * t) ^ r)));
+        ra[r] = pinned(lds_offset(buf + 8 * r + (t ^ r)));
+        const int c = t + 8 * r;
         const int q = GUARD ? data_classes_below64(c) : c;
-        bitoff[m] = (carrier_class64(c, GUARD) == 0) ? (s * ND + q) * BPS : -1;
+        const int bo = (s * ND + q) * BPS;
+        const bool data = carrier_class64(c, GUARD) == 0;
+        fa[r] = pinned(lds_offset(img + (bo >> 5)));
+        fs[r] = pinned(data ? (unsigned)(bo & 31) : 0xFFFFFFFFu);
     }
-    const int wr = swz(8 * t);      // first-pass write base (r is XOR-ed in below)
     const int lane_off = s * S + t; // sample offset of this lane inside the 8-symbol group
 
     // wave-uniform iteration state (no division in the loop: the host supplies the per-step increments)
@@ -83,19 +100,48 @@ __global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
     kk %= p.groups_per_frame;
     long long g_idx = (long long)blockIdx.x * 4 + wave;
 
-    // (A register prefetch of the next group's samples was measured in round 2: +22 VGPRs, 4 instead of 5 waves per SIMD,
-    // no change in time -- the kernel already sits at the practical DRAM rate)
-    for (; g_idx < p.n_groups; g_idx += p.stride_groups) {
+    // (A register prefetch of the next group's samples was measured in round 2: +22 VGPRs, no change in time; what moved the
+    // kernel was fewer VALU instructions per group -- DESIGN.md section 6.)
+    cf pre[8]; // PF: the next group's samples, fetched before this group is transformed
+    if (PF && g_idx < p.n_groups) {
         const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + kk * 8) * S + CP + lane_off;
-        cf v[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = src[8 * m];
+        for (int m = 0; m < 8; ++m) pre[m] = src[8 * m];
+    }
+    for (; g_idx < p.n_groups; g_idx += p.stride_groups) {
+        cf v[8];
+        long long f_out = f;
+        int kk_out = kk;
+        if (PF) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = pre[m];
+            f += p.step_df;
+            kk += p.step_dk;
+            if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; }
+            if (g_idx + p.stride_groups < p.n_groups) {
+                const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + kk * 8) * S + CP + lane_off;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) pre[m] = src[8 * m];
+            }
+        } else {
+            const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + kk * 8) * S + CP + lane_off;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = src[8 * m];
+        }
 
         bfly8<false>(v);
+        if (p.debug == 3) { // profiling aid: loads + one butterfly, one dword out per lane and group so that nothing is dead
+            float acc = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];   // swz(8t + r) = 8t + (r ^ t) = swz(8t) ^ r
+            for (int m = 0; m < 8; ++m) acc += v[m].x + v[m].y;
+            if (acc == 12345.678f) p.out[0] = 1;
+            if (!PF) { f += p.step_df; kk += p.step_dk; if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; } }
+            continue;
+        }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)]; // swz(t + 8m): (i >> 3) & 7 = m
+        for (int r = 0; r < 8; ++r) *(lds_cf_ptr)(unsigned long)wa[r] = f32x2{v[r].x, v[r].y};
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { const f32x2 q = *(lds_cf_ptr)(unsigned long)ra[m]; v[m] = make_float2(q.x, q.y); }
 #pragma unroll
         for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
         bfly8<false>(v);
@@ -115,12 +161,20 @@ __global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
             pv = (t == 7) ? v[4] : pv;
             pv = (t == 2) ? v[7] : pv;
             // angles kept in units of pi: atan2pi / sincospi need no large-argument reduction
-            const float ang = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.25f;
-            float sn, cs;
-            sincospif(ang, &sn, &cs);
-            const cf rot = make_float2(cs, -sn);
+            // mean angle in TURNS (sum of the four atan2pi values / 8), then the hardware sine / cosine, which take turns:
+            // max abs error 1.3e-7 over [-pi, pi] on gfx950 (tools/trig_probe.cpp; sincospif: 5e-8) for 2 instructions instead of ~35
+            const float turns = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.125f;
+            const cf rot = make_float2(__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns));
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
+        }
+        if (p.debug == 2) { // profiling aid: everything but the packing and the stores
+            float acc = 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc += v[m].x + v[m].y;
+            if (acc == 12345.678f) p.out[0] = 1;
+            if (!PF) { f += p.step_df; kk += p.step_dk; if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; } }
+            continue;
         }
         // clear the packed image, OR every field in, store it
         for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
@@ -129,22 +183,33 @@ __global__ __launch_bounds__(256) void k_demod64(Fast64Params p) {
             // bins t + 8 m with m in {1, 2, 5, 6} are data carriers for every lane (the nulls and pilots sit in rows 0, 3, 4, 7):
             // no per-lane test, no exec-mask juggling for half of the fields
             const bool all_data = !GUARD || m == 1 || m == 2 || m == 5 || m == 6;
-            if (all_data || bitoff[m] >= 0) {
+            if (all_data || fs[m] != 0xFFFFFFFFu) {
                 const unsigned idx = demap_point(v[m], BPS);
-                const int wd = bitoff[m] >> 5, sh = bitoff[m] & 31;
-                atomicOr(&img[wd], idx << sh);
+                const lds_u32_ptr wd = (lds_u32_ptr)(unsigned long)fa[m];
+                __hip_atomic_fetch_or(wd, idx << fs[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)
-                    if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
+                    if (fs[m] + BPS > 32) __hip_atomic_fetch_or(wd + 1, idx >> (32 - fs[m]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
-        unsigned *dst = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)kk * 8 * (ND * BPS / 8));
-        for (int i = lane; i < REGION_DW; i += 64) dst[i] = img[i];
+        unsigned *dst = reinterpret_cast<unsigned *>(p.out + f_out * p.out_stride + (long long)kk_out * 8 * (ND * BPS / 8));
+        if (p.debug == 1) { if (img[lane] == 0x12345678u) dst[0] = 1u; } // profiling aid: no stores
+        else if (p.debug == 4) { // profiling aid: every store lands in one small L2-resident window (no HBM writes)
+            unsigned *d2 = reinterpret_cast<unsigned *>(p.out) + (g_idx & 1023) * REGION_DW;
+            for (int i = lane; i < REGION_DW; i += 64) d2[i] = img[i];
+        } else if (p.debug == 5) { // profiling aid: nontemporal stores
+            for (int i = lane; i < REGION_DW; i += 64) __builtin_nontemporal_store(img[i], dst + i);
+        } else if (REGION_DW % 4 == 0 && p.wide_stores) {
+            // 16 bytes per lane: a 288-byte region leaves as ONE instruction with 18 active lanes instead of 64 + 8 lanes of 4 bytes
+            // (measured: the dword stores cost 0.39 of the kernel's 1.81 ms -- store issue, not HBM write bandwidth)
+            for (int i = lane; i < REGION_DW / 4; i += 64) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(img)[i];
+        } else for (int i = lane; i < REGION_DW; i += 64) dst[i] = img[i];
 
-        // advance (wave-uniform)
-        f += p.step_df;
-        kk += p.step_dk;
-        if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; }
+        if (!PF) { // advance (wave-uniform)
+            f += p.step_df;
+            kk += p.step_dk;
+            if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; }
+        }
     }
 }
 
@@ -1137,7 +1202,14 @@ template <typename K> static int resident_blocks(K kernel, int block) {
     return cached[dev];
 }
 template <int BPS, bool GUARD, bool HK> static hipError_t launch_demod64(Fast64Params p, hipStream_t st, int num_cu) {
-    auto kernel = k_demod64<BPS, GUARD, HK>;
+    static const bool pf = getenv("OFDM_DEMOD64_PF") != nullptr; // A/B: register prefetch of the next group (config-2 variant only)
+    { static const int dbg = [] { const char *v = getenv("OFDM_DEMOD64_DEBUG"); return v ? atoi(v) : 0; }(); p.debug = dbg; }
+    {   // 16-byte stores need 16-byte aligned group regions: base, frame stride and the 8-symbol region itself
+        static const bool narrow = getenv("OFDM_DEMOD64_NARROW_STORES") != nullptr; // A/B
+        constexpr int region_bytes = (GUARD ? 48 : 64) * BPS;
+        p.wide_stores = !narrow && region_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_stride & 15) == 0;
+    }
+    auto kernel = (BPS == 6 && GUARD && !HK && pf) ? k_demod64<6, true, false, true> : k_demod64<BPS, GUARD, HK>;
     long long waves = (p.n_groups + 3) / 4 * 4;
     static const int knob = [] { const char *v = getenv("OFDM_DEMOD64_WG_PER_CU"); return v ? atoi(v) : 0; }(); // tuning knob
     const long long cap = (long long)num_cu * (knob > 0 ? knob : (resident_blocks(kernel, 256) >= 4 ? 8 : 2 * resident_blocks(kernel, 256))) * 4;
