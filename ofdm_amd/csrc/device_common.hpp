@@ -203,6 +203,16 @@ __device__ __forceinline__ unsigned axis_bits(float x, int m) {
         }
         return __builtin_amdgcn_ubfe(lut, l * (unsigned)m, (unsigned)m);
     }
+    if (m == 4) { // 16 entries x 4 bits: two 32-bit halves of the same table
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned g = (unsigned)i ^ ((unsigned)i >> 1);
+            const unsigned r = ((g & 1u) << 3) | ((g & 2u) << 1) | ((g & 4u) >> 1) | ((g & 8u) >> 3);
+            if (i < 8) lo |= r << (4 * i); else hi |= r << (4 * (i - 8));
+        }
+        return __builtin_amdgcn_ubfe(l < 8u ? lo : hi, (l & 7u) * 4u, 4u);
+    }
     const unsigned g = l ^ (l >> 1);           // Gray code, MSB = first stream bit
     return __brev(g) >> (32 - m);              // first stream bit at bit 0
 }

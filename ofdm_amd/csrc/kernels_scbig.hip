@@ -29,8 +29,8 @@ namespace ofdm {
 namespace {
 
 constexpr int B_TILE = 2560;   // samples per chunk-sum tile (256 threads x 10)
-constexpr int F_TILE = 1280;   // lags per fine tile (128 threads x 10)
-constexpr int F_WG = 128;
+constexpr int F_WG = 64;        // one wavefront per frame: 20 KB of LDS, 7 frames in flight per CU (128 threads / 1280 lags: 3 per CU, 25 % slower)
+constexpr int F_TILE = 10 * F_WG; // lags per fine tile
 
 struct BSums { double pr, pi, e, r; };
 __device__ __forceinline__ BSums bs_add(BSums a, BSums b) { return BSums{a.pr + b.pr, a.pi + b.pi, a.e + b.e, a.r + b.r}; }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
             if (lane == 63) wsum[wave] = inc;
             __syncthreads();
             BSums base = boundary((int)(d0 / C));
-            if (wave == 1) base = bs_add(base, wsum[0]);
+            for (int wv = 0; wv < wave; ++wv) base = bs_add(base, wsum[wv]);
             {
                 const BSums ex = BSums{__shfl_up(inc.pr, 1, 64), __shfl_up(inc.pi, 1, 64), __shfl_up(inc.e, 1, 64), __shfl_up(inc.r, 1, 64)};
                 if (lane > 0) base = bs_add(base, ex);
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
                 for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(mine, sft, 64); mine = o < mine ? o : mine; }
                 if (lane == 0) wmin[wave] = mine;
                 __syncthreads();
-                const int m = wmin[0] < wmin[1] ? wmin[0] : wmin[1];
+                int m = wmin[0];
+                for (int wv = 1; wv < F_WG / 64; ++wv) m = wmin[wv] < m ? wmin[wv] : m;
                 if (m != INT_MAX) { cross = d0 + m; lo = cross; if (hi > cross + W) hi = cross + W; }
                 cross_out = cross;
                 if (m == INT_MAX) return; // wave-uniform: no crossing in this tile, nothing to maximise yet
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
             for (int sft = 32; sft >= 1; sft >>= 1) mineb = bc_pick(mineb, bc_shfl_xor(mineb, sft));
             if (lane == 0) wcand[wave] = mineb;
             __syncthreads();
-            best = bc_pick(best, bc_pick(wcand[0], wcand[1]));
+            for (int wv = 0; wv < F_WG / 64; ++wv) best = bc_pick(best, wcand[wv]);
         };
 
         // ---- first crossing: chunks whose bound reaches the threshold, in lag order
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
             for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(cn, sft, 64); cn = o < cn ? o : cn; }
             if (lane == 0) shi[wave] = cn;
             __syncthreads();
-            cn = shi[0] < shi[1] ? shi[0] : shi[1];
+            cn = shi[0];
+            for (int wv = 1; wv < F_WG / 64; ++wv) cn = shi[wv] < cn ? shi[wv] : cn;
             __syncthreads();
             if (cn == INT_MAX) break;
             tile0 = (long long)cn * C;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
             for (int sft = 32; sft >= 1; sft >>= 1) bb = bc_pick(bb, bc_shfl_xor(bb, sft));
             if (lane == 0) wcand[wave] = bb;
             __syncthreads();
-            best = bc_pick(best, bc_pick(wcand[0], wcand[1]));
+            for (int wv = 0; wv < F_WG / 64; ++wv) best = bc_pick(best, wcand[wv]);
             __syncthreads();
         }
         for (long long t = tile0 + F_TILE; t <= dend; t += F_TILE) {
@@ -352,7 +354,7 @@ hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_
         if (e != hipSuccess) return e;
     }
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
-    if (per_cu > 6) per_cu = 6;
+    if (per_cu > 8) per_cu = 8;
     long long g2 = (long long)num_cu * per_cu;
     if (g2 > p.n_frames) g2 = p.n_frames;
     hipLaunchKernelGGL(k_scb_fine, dim3((unsigned)g2), dim3(F_WG), lds, st, q);
