@@ -362,10 +362,8 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
                 pv = (t == 1) ? v[3] : pv;
                 pv = (t == 7) ? v[4] : pv;
                 pv = (t == 2) ? v[7] : pv;
-                const float ang = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.25f;
-                float sn, cs;
-                sincospif(ang, &sn, &cs);
-                const cf rot = make_float2(cs, -sn);
+                const float trn = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.125f; // mean pilot angle in turns -> hardware sin / cos
+                const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
             }
@@ -782,9 +780,8 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
             float tot = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) tot += red[i];
-            float sn, cs;
-            sincospif(tot * (1.0f / 256.0f), &sn, &cs);
-            const cf rot = make_float2(cs, -sn);
+            const float trn = tot * (0.5f / 256.0f); // mean of the 256 pilot angles, in turns -> hardware sin / cos
+            const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
         }
@@ -1008,9 +1005,8 @@ __global__ __launch_bounds__(128, 2) void k_rxframe1024(RxFrame1024Params p) {
                 for (int sh = 32; sh >= 1; sh >>= 1) a += __shfl_xor(a, sh, 64);
                 if (lane == 0) red[wave] = a;
                 __syncthreads();
-                float sn, cs;
-                sincospif((red[0] + red[1]) * (1.0f / 64.0f), &sn, &cs);
-                const cf rot = make_float2(cs, -sn);
+                const float trn = (red[0] + red[1]) * (0.5f / 64.0f); // mean of the 64 pilot angles, in turns
+                const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
             }

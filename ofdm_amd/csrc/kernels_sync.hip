@@ -832,10 +832,8 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                     pv = (t == 1) ? v[3] : pv;
                     pv = (t == 7) ? v[4] : pv;
                     pv = (t == 2) ? v[7] : pv;
-                    const float ang = sum8_lanes(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.25f;
-                    float sn, cs;
-                    sincospif(ang, &sn, &cs);
-                    const cf rot = make_float2(cs, -sn);
+                    const float trn = sum8_lanes(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.125f; // mean pilot angle in turns
+                    const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
 #pragma unroll
                     for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
                 }
