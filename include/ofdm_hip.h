@@ -171,7 +171,11 @@ int ofdm_rs255_decode(const uint8_t *code, int64_t n_code, uint8_t *out, int32_t
 /* Schmidl-Cox sliding autocorrelation (north-star extension replacing xcorr_fft timing, receiver.rs:20-25).
  * Frame f occupies in_dev[f*frame_stride .. +frame_len).  Lags d in [0, n_lags) (n_lags <= 0: every lag with
  * d + W + L <= frame_len).  d_hat = first max of M over [d1, d1+W], d1 = first lag with M >= threshold;
- * d_hat[f] = -1 if none.  f_delta[f] = arg P(d_hat)/L (signed, rad/sample), metric[f] = M(d_hat). */
+ * d_hat[f] = -1 if none.  f_delta[f] = arg P(d_hat)/L (signed, rad/sample), metric[f] = M(d_hat).
+ * n_lags bounds the peak window too: it is [d1, min(d1 + W, n_lags - 1)], so a bounded search returns an earlier lag than the
+ * full one whenever the true peak lies beyond n_lags - 1 (same rule in the oracle; tests: test_bounded_search_clips_the_peak_window).
+ * Any n_fft is served: L = 80 by the one-tile f32-filter / f64-decision kernel, L >= 160 by streaming chunk sums and a bounded
+ * exact search whose LDS footprint does not depend on L (N = 4096 included). */
 int ofdm_sc_correlate_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frames, int64_t frame_stride,
                             int64_t frame_len, int64_t n_lags, int32_t *d_hat_dev, double *f_delta_dev,
                             float *metric_dev);
