@@ -46,7 +46,10 @@ __device__ __forceinline__ unsigned lds_offset(const void *p) {
 // that produced it inside the loop (to stay under 96 VGPRs), once per use and iteration.
 __device__ __forceinline__ unsigned pinned(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
-template <int BPS, bool GUARD, bool HK, bool PF = false>
+// BURST: a wavefront takes BURST consecutive 8-symbol groups per step and stores their packed images together -- for the
+// 288-byte images of 64-QAM with guard bands, 4 groups = 1152 bytes = nine WHOLE 128-byte lines (one group's image starts at
+// a multiple of 288 bytes: 2.25 lines, shared with the neighbours).  Needs a contiguous output (rows back to back).
+template <int BPS, bool GUARD, bool HK, int BURST = 1>
 __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
     constexpr int N = 64, S = 80, CP = 16;
     constexpr int ND = GUARD ? 48 : 64;          // data carriers per symbol
@@ -54,13 +57,13 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
     constexpr int SLAB = 8 * 72;                 // 8 symbols x (64 + 8 pad) points
 
     __shared__ cf slab_all[4 * SLAB];
-    __shared__ __align__(16) unsigned img_all[4 * REGION_DW];
+    __shared__ __align__(16) unsigned img_all[4 * BURST * REGION_DW];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = lane >> 3, t = lane & 7;
     cf *buf = slab_all + wave * SLAB + s * 72;
-    unsigned *img = img_all + wave * REGION_DW;
+    unsigned *img0 = img_all + wave * BURST * REGION_DW;
 
     // loop-invariant per-lane constants
     cf w[7];
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
     }
     // LDS byte addresses of the transpose (write: swz(8t + r) = 8t + (r ^ t); read: swz(t + 8m) = 8m + (t ^ m)) and of every
     // field's dword in the packed image, with the field's shift: 8 + 8 + 8 + 8 registers instead of ~5 integer instructions
-    // per access and iteration (the kernel runs at 4 waves per SIMD either way: measured insensitive between 4 and 5)
+    // per access and iteration
     unsigned wa[8], ra[8], fa[8], fs[8]; // fs: bit shift inside the dword, 0xFFFFFFFF = not a data bin
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -87,56 +90,24 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
         const int q = GUARD ? data_classes_below64(c) : c;
         const int bo = (s * ND + q) * BPS;
         const bool data = carrier_class64(c, GUARD) == 0;
-        fa[r] = pinned(lds_offset(img + (bo >> 5)));
+        fa[r] = pinned(lds_offset(img0 + (bo >> 5)));
         fs[r] = pinned(data ? (unsigned)(bo & 31) : 0xFFFFFFFFu);
     }
     const int lane_off = s * S + t; // sample offset of this lane inside the 8-symbol group
 
-    // wave-uniform iteration state (no division in the loop: the host supplies the per-step increments)
-    long long f = p.f0 + (long long)blockIdx.x * p.blk_df + wave * p.wave_df;
-    int kk = p.k0 + (int)((blockIdx.x * (long long)p.blk_dk + wave * p.wave_dk));
-    // normalise kk into [0, groups_per_frame)
-    f += kk / p.groups_per_frame;
-    kk %= p.groups_per_frame;
-    long long g_idx = (long long)blockIdx.x * 4 + wave;
-
-    // (A register prefetch of the next group's samples was measured in round 2: +22 VGPRs, no change in time; what moved the
-    // kernel was fewer VALU instructions per group -- DESIGN.md section 6.)
-    cf pre[8]; // PF: the next group's samples, fetched before this group is transformed
-    if (PF && g_idx < p.n_groups) {
+    // one 8-symbol group: CP strip + FFT64 + [equalise] + pilot phase + demap + packing into the LDS image at byte offset img_off
+    auto group = [&](long long f, int kk, unsigned img_off) {
         const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + kk * 8) * S + CP + lane_off;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) pre[m] = src[8 * m];
-    }
-    for (; g_idx < p.n_groups; g_idx += p.stride_groups) {
         cf v[8];
-        long long f_out = f;
-        int kk_out = kk;
-        if (PF) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = pre[m];
-            f += p.step_df;
-            kk += p.step_dk;
-            if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; }
-            if (g_idx + p.stride_groups < p.n_groups) {
-                const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + kk * 8) * S + CP + lane_off;
-#pragma unroll
-                for (int m = 0; m < 8; ++m) pre[m] = src[8 * m];
-            }
-        } else {
-            const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + kk * 8) * S + CP + lane_off;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = src[8 * m];
-        }
-
+        for (int m = 0; m < 8; ++m) v[m] = src[8 * m];
         bfly8<false>(v);
-        if (p.debug == 3) { // profiling aid: loads + one butterfly, one dword out per lane and group so that nothing is dead
+        if (p.debug == 3) { // profiling aid: loads + one butterfly
             float acc = 0.f;
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc += v[m].x + v[m].y;
             if (acc == 12345.678f) p.out[0] = 1;
-            if (!PF) { f += p.step_df; kk += p.step_dk; if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; } }
-            continue;
+            return;
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) *(lds_cf_ptr)(unsigned long)wa[r] = f32x2{v[r].x, v[r].y};
@@ -146,7 +117,6 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
         for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
         bfly8<false>(v);
         // v[m] = X[t + 8m]
-
         if (HK) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], g[m]);
@@ -160,7 +130,6 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
             pv = (t == 1) ? v[3] : pv;
             pv = (t == 7) ? v[4] : pv;
             pv = (t == 2) ? v[7] : pv;
-            // angles kept in units of pi: atan2pi / sincospi need no large-argument reduction
             // mean angle in TURNS (sum of the four atan2pi values / 8), then the hardware sine / cosine, which take turns:
             // max abs error 1.3e-7 over [-pi, pi] on gfx950 (tools/trig_probe.cpp; sincospif: 5e-8) for 2 instructions instead of ~35
             const float turns = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.125f;
@@ -173,10 +142,10 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc += v[m].x + v[m].y;
             if (acc == 12345.678f) p.out[0] = 1;
-            if (!PF) { f += p.step_df; kk += p.step_dk; if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; } }
-            continue;
+            return;
         }
-        // clear the packed image, OR every field in, store it
+        // clear the packed image, OR every field in
+        unsigned *img = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(img0) + img_off);
         for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -185,31 +154,53 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
             const bool all_data = !GUARD || m == 1 || m == 2 || m == 5 || m == 6;
             if (all_data || fs[m] != 0xFFFFFFFFu) {
                 const unsigned idx = demap_point(v[m], BPS);
-                const lds_u32_ptr wd = (lds_u32_ptr)(unsigned long)fa[m];
+                const lds_u32_ptr wd = (lds_u32_ptr)(unsigned long)(fa[m] + img_off);
                 __hip_atomic_fetch_or(wd, idx << fs[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)
                     if (fs[m] + BPS > 32) __hip_atomic_fetch_or(wd + 1, idx >> (32 - fs[m]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
-        unsigned *dst = reinterpret_cast<unsigned *>(p.out + f_out * p.out_stride + (long long)kk_out * 8 * (ND * BPS / 8));
-        if (p.debug == 1) { if (img[lane] == 0x12345678u) dst[0] = 1u; } // profiling aid: no stores
-        else if (p.debug == 4) { // profiling aid: every store lands in one small L2-resident window (no HBM writes)
-            unsigned *d2 = reinterpret_cast<unsigned *>(p.out) + (g_idx & 1023) * REGION_DW;
-            for (int i = lane; i < REGION_DW; i += 64) d2[i] = img[i];
-        } else if (p.debug == 5) { // profiling aid: nontemporal stores
-            for (int i = lane; i < REGION_DW; i += 64) __builtin_nontemporal_store(img[i], dst + i);
-        } else if (REGION_DW % 4 == 0 && p.wide_stores) {
-            // 16 bytes per lane: a 288-byte region leaves as ONE instruction with 18 active lanes instead of 64 + 8 lanes of 4 bytes
-            // (measured: the dword stores cost 0.39 of the kernel's 1.81 ms -- store issue, not HBM write bandwidth)
-            for (int i = lane; i < REGION_DW / 4; i += 64) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(img)[i];
-        } else for (int i = lane; i < REGION_DW; i += 64) dst[i] = img[i];
+    };
+    auto store_image = [&](unsigned *dst, int ndw) { // ndw dwords of this wave's LDS image -> global
+        if (p.debug == 1 || p.debug == 2 || p.debug == 3) { if (img0[lane] == 0x12345678u) dst[0] = 1u; return; } // profiling aid: no stores
+        if (p.debug == 4) dst = reinterpret_cast<unsigned *>(p.out) + (blockIdx.x & 255) * 4 * BURST * REGION_DW + wave * BURST * REGION_DW; // L2-resident window
+        if (p.debug == 5) { for (int i = lane; i < ndw; i += 64) __builtin_nontemporal_store(img0[i], dst + i); return; }
+        if ((REGION_DW % 4) == 0 && p.wide_stores) { // 16 bytes per lane
+            for (int i = lane; i < ndw / 4; i += 64) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(img0)[i];
+        } else for (int i = lane; i < ndw; i += 64) dst[i] = img0[i];
+    };
 
-        if (!PF) { // advance (wave-uniform)
-            f += p.step_df;
-            kk += p.step_dk;
-            if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; }
+    if (BURST > 1) {
+        // wave-uniform: burst j of this wave = groups [BURST j, BURST (j + 1)); one 64-bit division per BURST groups
+        const long long n_bursts = p.n_groups / BURST; // the launcher guarantees divisibility and a contiguous output
+        for (long long j = (long long)blockIdx.x * 4 + wave; j < n_bursts; j += p.stride_groups) {
+            const long long g0 = j * BURST;
+            long long f = g0 / p.groups_per_frame;
+            int kk = (int)(g0 - f * p.groups_per_frame);
+#pragma nounroll
+            for (int b = 0; b < BURST; ++b) {
+                group(f, kk, (unsigned)(b * REGION_DW * 4));
+                if (++kk == p.groups_per_frame) { kk = 0; ++f; }
+            }
+            store_image(reinterpret_cast<unsigned *>(p.out + g0 * (long long)(REGION_DW * 4)), BURST * REGION_DW);
         }
+        return;
+    }
+
+    // wave-uniform iteration state (no division in the loop: the host supplies the per-step increments)
+    long long f = p.f0 + (long long)blockIdx.x * p.blk_df + wave * p.wave_df;
+    int kk = p.k0 + (int)((blockIdx.x * (long long)p.blk_dk + wave * p.wave_dk));
+    // normalise kk into [0, groups_per_frame)
+    f += kk / p.groups_per_frame;
+    kk %= p.groups_per_frame;
+    for (long long g_idx = (long long)blockIdx.x * 4 + wave; g_idx < p.n_groups; g_idx += p.stride_groups) {
+        group(f, kk, 0u);
+        store_image(reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)kk * 8 * (ND * BPS / 8)), REGION_DW);
+        // advance (wave-uniform)
+        f += p.step_df;
+        kk += p.step_dk;
+        if (kk >= p.groups_per_frame) { kk -= p.groups_per_frame; f += 1; }
     }
 }
 
@@ -1226,15 +1217,19 @@ template <typename K> static int resident_blocks(K kernel, int block) {
     return cached[dev];
 }
 template <int BPS, bool GUARD, bool HK> static hipError_t launch_demod64(Fast64Params p, hipStream_t st, int num_cu) {
-    static const bool pf = getenv("OFDM_DEMOD64_PF") != nullptr; // A/B: register prefetch of the next group (config-2 variant only)
     { static const int dbg = [] { const char *v = getenv("OFDM_DEMOD64_DEBUG"); return v ? atoi(v) : 0; }(); p.debug = dbg; }
+    constexpr int region_bytes = (GUARD ? 48 : 64) * BPS;
     {   // 16-byte stores need 16-byte aligned group regions: base, frame stride and the 8-symbol region itself
         static const bool narrow = getenv("OFDM_DEMOD64_NARROW_STORES") != nullptr; // A/B
-        constexpr int region_bytes = (GUARD ? 48 : 64) * BPS;
         p.wide_stores = !narrow && region_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_stride & 15) == 0;
     }
-    auto kernel = (BPS == 6 && GUARD && !HK && pf) ? k_demod64<6, true, false, true> : k_demod64<BPS, GUARD, HK>;
-    long long waves = (p.n_groups + 3) / 4 * 4;
+    // burst mode (config-2 shape only: the template is instantiated once): 4 groups per step, whole-line stores
+    static const bool no_burst = getenv("OFDM_DEMOD64_NO_BURST") != nullptr; // A/B
+    const bool burst = BPS == 6 && GUARD && !HK && !no_burst && p.wide_stores && p.n_groups % 4 == 0 &&
+                       p.out_stride == (long long)p.groups_per_frame * region_bytes && (reinterpret_cast<uintptr_t>(p.out) & 127) == 0;
+    auto kernel = burst ? k_demod64<6, true, false, 4> : k_demod64<BPS, GUARD, HK, 1>;
+    const long long units = burst ? p.n_groups / 4 : p.n_groups;
+    long long waves = (units + 3) / 4 * 4;
     static const int knob = [] { const char *v = getenv("OFDM_DEMOD64_WG_PER_CU"); return v ? atoi(v) : 0; }(); // tuning knob
     const long long cap = (long long)num_cu * (knob > 0 ? knob : (resident_blocks(kernel, 256) >= 4 ? 8 : 2 * resident_blocks(kernel, 256))) * 4;
     if (waves > cap) waves = cap;
