@@ -75,10 +75,27 @@ __device__ __forceinline__ void stage_segments(cf *const *dst, const cf *frame, 
 
 } // namespace
 
-// ---- chunk totals: ws[f][0 .. nch) = sum q.re, [nch .. 2 nch) = sum q.im, [2 nch .. 3 nch) = sum e   (doubles)
+// ---- chunk totals: ws[f][0 .. nch) = sum q.re, [nch_pad ..) = sum q.im, [2 nch_pad ..) = sum e   (doubles)
+// Two stagings: L <= 1280 (N <= 1024): ONE contiguous span of 5120 + L samples per item (the partner sample n + L lives in the
+// same LDS image: 1.25 global reads per sample instead of 2; two micro-chunks per thread); longer periods: the tile of 2560
+// samples and its partner tile L samples later as two separate segments (LDS footprint independent of L).
+__device__ __forceinline__ void chunk_sums(const cf *a, const cf *b, double &qr, double &qi, double &e) {
+    const float4 *pa = reinterpret_cast<const float4 *>(a), *pb = reinterpret_cast<const float4 *>(b);
+    qr = 0.0; qi = 0.0; e = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float4 x = pa[i], y = pb[i];
+        const double ar = x.x, ai = x.y, br = y.x, bi = y.y, cr = x.z, ci = x.w, dr = y.z, di = y.w;
+        qr += ar * br + ai * bi; qi += ar * bi - ai * br; e += ar * ar + ai * ai;
+        qr += cr * dr + ci * di; qi += cr * di - ci * dr; e += cr * cr + ci * ci;
+    }
+}
+template <bool CONTIG>
 __global__ __launch_bounds__(256) void k_scb_chunks(ScBigParams p) {
-    __shared__ __align__(16) cf seg_a[B_TILE];
-    __shared__ __align__(16) cf seg_b[B_TILE];
+    extern __shared__ __align__(16) unsigned char smem_c[];
+    cf *seg_a = reinterpret_cast<cf *>(smem_c);       // CONTIG: [2 B_TILE + L]; else [B_TILE]
+    cf *seg_b = seg_a + B_TILE;                       // !CONTIG: [B_TILE] the partner tile
+    constexpr int TILE = CONTIG ? 2 * B_TILE : B_TILE;
     const int tid = threadIdx.x;
     const int k = p.C / 10;                  // micro-chunks per chunk: N / 64, a power of two <= 64
     const long long items = p.n_frames * (long long)p.tiles_per_frame;
@@ -86,33 +103,48 @@ __global__ __launch_bounds__(256) void k_scb_chunks(ScBigParams p) {
         const long long f = it / p.tiles_per_frame;
         const int tile = (int)(it - f * p.tiles_per_frame);
         const cf *frame = p.in + f * p.frame_stride;
-        const long long t0 = (long long)tile * B_TILE;
+        const long long t0 = (long long)tile * TILE;
         __syncthreads(); // the previous item's readers are done
-        {
+        if (CONTIG) {
+            // (2 B_TILE + L) / 2 float4 per item, L <= 1280: 13 loads per thread at most, all issued before the first LDS store
+            const int n4 = (TILE + p.L) / 2;
+            const long long avail = p.frame_len - t0;
+            const bool al = (reinterpret_cast<uintptr_t>(frame + t0) & 15) == 0;
+            float4 x[13];
+#pragma unroll
+            for (int j = 0; j < 13; ++j) {
+                const int i = tid + j * 256;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n4) {
+                    if (2 * i + 1 < avail) {
+                        if (al) v = reinterpret_cast<const float4 *>(frame + t0)[i];
+                        else { const cf a = frame[t0 + 2 * i], b = frame[t0 + 2 * i + 1]; v = make_float4(a.x, a.y, b.x, b.y); }
+                    } else if (2 * i < avail) { const cf a = frame[t0 + 2 * i]; v.x = a.x; v.y = a.y; }
+                }
+                x[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 13; ++j) { const int i = tid + j * 256; if (i < n4) reinterpret_cast<float4 *>(seg_a)[i] = x[j]; }
+        } else {
             cf *const dsts[2] = {seg_a, seg_b};
             const long long firsts[2] = {t0, t0 + p.L};
             stage_segments<2, B_TILE / 2 / 256>(dsts, frame, firsts, p.frame_len, tid, 256);
         }
         __syncthreads();
-        double qr = 0.0, qi = 0.0, e = 0.0;
-        {
-            const float4 *pa = reinterpret_cast<const float4 *>(seg_a + tid * 10), *pb = reinterpret_cast<const float4 *>(seg_b + tid * 10);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const float4 x = pa[i], y = pb[i];
-                const double ar = x.x, ai = x.y, br = y.x, bi = y.y, cr = x.z, ci = x.w, dr = y.z, di = y.w;
-                qr += ar * br + ai * bi; qi += ar * bi - ai * br; e += ar * ar + ai * ai;
-                qr += cr * dr + ci * di; qi += cr * di - ci * dr; e += cr * cr + ci * ci;
+        for (int u = 0; u < (CONTIG ? 2 : 1); ++u) {
+            const int mc = tid + 256 * u;        // micro-chunk of 10 samples inside the tile
+            double qr, qi, e;
+            chunk_sums(seg_a + mc * 10, CONTIG ? seg_a + mc * 10 + p.L : seg_b + mc * 10, qr, qi, e);
+            for (int sft = 1; sft < k; sft <<= 1) { // k consecutive lanes -> one chunk (k <= 64: inside the wavefront)
+                qr += __shfl_xor(qr, sft, 64); qi += __shfl_xor(qi, sft, 64); e += __shfl_xor(e, sft, 64);
             }
-        }
-        for (int sft = 1; sft < k; sft <<= 1) { // k consecutive lanes -> one chunk (k <= 64: inside the wavefront)
-            qr += __shfl_xor(qr, sft, 64); qi += __shfl_xor(qi, sft, 64); e += __shfl_xor(e, sft, 64);
-        }
-        if ((tid & (k - 1)) == 0) {
-            const int c = (int)(t0 / p.C) + tid / k;
-            if (c < p.nch) {
-                double *w = p.ws + f * 3LL * p.nch_pad;
-                w[c] = qr; w[p.nch_pad + c] = qi; w[2 * p.nch_pad + c] = e;
+            if ((tid & (k - 1)) == 0) {
+                const int c = (int)(t0 / p.C) + mc / k;
+                if (c < p.nch) {
+                    double *w = p.ws + f * 3LL * p.nch_pad;
+                    w[c] = qr; w[p.nch_pad + c] = qi; w[2 * p.nch_pad + c] = e;
+                }
             }
         }
     }
@@ -338,14 +370,21 @@ hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_
     q.L = p.L; q.W = p.W; q.C = p.L / 8; q.threshold = p.threshold;
     q.nch = (int)((p.n_lags + p.W + p.L + q.C - 1) / q.C + 1);
     q.nch_pad = (q.nch + 1 + 7) / 8 * 8;
-    q.tiles_per_frame = (int)(((long long)q.nch * q.C + B_TILE - 1) / B_TILE);
+    const bool contig = p.L <= 1280 && getenv("OFDM_SCB_TWO_SEGMENTS") == nullptr; // the partner sample fits the same LDS image
+    const int tile = contig ? 2 * B_TILE : B_TILE;
+    q.tiles_per_frame = (int)(((long long)q.nch * q.C + tile - 1) / tile);
     q.ws = reinterpret_cast<double *>(workspace);
     q.d_hat = p.d_hat; q.f_delta = p.f_delta; q.metric = p.metric;
     const long long items = p.n_frames * (long long)q.tiles_per_frame;
-    long long g1 = (long long)num_cu * 4; // 40 KB of LDS per workgroup
+    const size_t lds1 = contig ? (size_t)(2 * B_TILE + p.L) * sizeof(float2) : (size_t)2 * B_TILE * sizeof(float2);
+    long long g1 = (long long)num_cu * ((long long)(160 * 1024) / (long long)lds1);
     if (g1 > items) g1 = items;
-    hipLaunchKernelGGL(k_scb_chunks, dim3((unsigned)g1), dim3(256), 0, st, q);
-    hipError_t e = hipGetLastError();
+    hipError_t e;
+    if (contig) {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scb_chunks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_scb_chunks<true>, dim3((unsigned)g1), dim3(256), lds1, st, q);
+    } else hipLaunchKernelGGL(k_scb_chunks<false>, dim3((unsigned)g1), dim3(256), lds1, st, q);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = (size_t)4 * (F_TILE + 16) * sizeof(float2) + (size_t)q.nch_pad * sizeof(float) + 2 * sizeof(BSums) +
                        2 * sizeof(BCand) + 4 * sizeof(int) + 64;
