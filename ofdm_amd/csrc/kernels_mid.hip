@@ -1,0 +1,506 @@
+// kernels_mid.hip -- symbol-stream RX demod and TX for the transform lengths between the two headline shapes:
+// N = 64 R, R in {2, 4, 8, 16, 32} (EXT-4: N = 128 .. 2048), as an R x 64 two-stage transform, the layout k_demod4096 /
+// k_tx4096 (kernels_fast.hip) use for R = 64:
+//     X[c + R d] = sum_b W64^(b d) * [ W_N^(b c) * sum_a x[64 a + b] W_R^(a c) ]          a, c < R;  b, d < 64
+//   stage A  the R-point transform over a for each of the 64 columns b, straight from HBM (64 consecutive columns = 512
+//            contiguous bytes per row a), eight points per lane:
+//              R <  8   a lane owns 8/R whole columns: radix-R butterflies in registers;
+//              R =  8   one column per lane: one radix-8 butterfly;
+//              R >  8   Q = R/8 adjacent lanes share a column: radix-8 in registers, W_R^(u j), radix-Q across the lanes by DPP
+//                       quad permutes (no LDS);
+//   twiddle  W_N^(b c): eight loop-invariant registers per lane;
+//   transpose through LDS: row slot rho(c) x column b, 72-sample rows;
+//   stage B  the FFT64 over b for each row c: 8 lanes x 8 points, wave-local (the k_demod64 layout);
+//   epilogue as k_demod4096: the carrier class of bin c + R d is class64(d) (src/receiver.rs:122-133 tiled N/64 times), so a
+//            lane's eight bins d = t + 8 q have the same classes for every row.
+// A symbol occupies 8 R lanes in both stages; a 256-thread workgroup carries 32 / R symbols per step.  For R <= 8 a symbol
+// lives inside one wavefront and every exchange is ordered by the in-order LDS pipe (a wavefront fence, no barrier).
+// Roofline: HBM, one read of every sample after the prefix (RX) / one write of every sample (TX); see DESIGN.md section 5.4.
+#include "device_common.hpp"
+#include "kernels.hpp"
+#include <stdlib.h>
+
+extern "C" __device__ float __ocml_atan2pi_f32(float, float); // atan2(y, x) / pi (ROCm device library)
+
+namespace ofdm {
+
+namespace {
+
+template <int CTRL> __device__ __forceinline__ float dppq(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ cf dppq_cf(cf a) { return make_float2(dppq<CTRL>(a.x), dppq<CTRL>(a.y)); }
+
+template <int R> struct Mid {
+    static constexpr int N = 64 * R, CP = N / 4, S = N + CP;
+    static constexpr int LPS = 8 * R;               // lanes per symbol
+    static constexpr int WG = 256;
+    static constexpr int G = WG / LPS;              // symbols per workgroup step
+    static constexpr int Q = R >= 8 ? R / 8 : 1;    // lanes per stage-A column
+    static constexpr int P = R >= 8 ? 1 : 8 / R;    // stage-A columns per lane
+    static constexpr int TS = 72, SLAB = 8 * 72;
+    // waves per SIMD (= workgroups per CU) the kernels are built for: the RX kernel for R >= 16 keeps 14 more constant
+    // registers and spills 10-20 of them under the 128-VGPR limit of 4 waves (measured: N = 1024 RX 0.30 -> 0.45 of the
+    // roofline at 3 waves, TX 0.49 -> 0.44 -- TX has no spills at 4)
+    static constexpr int OCC_RX = R >= 16 ? 3 : 4, OCC_TX = 4;
+    // row slot of output row c in the transpose buffer: the Q lanes of a column write ADJACENT rows (16 banks apart)
+    __device__ static int slot_of_row(int c) { return R >= 8 ? (c & 7) * Q + (c >> 3) : c; }
+    __device__ static int row_of_slot(int rho) { return R >= 8 ? rho / Q + 8 * (rho % Q) : rho; }
+};
+
+template <int LPS> __device__ __forceinline__ void symbol_sync() {
+    if (LPS > 64) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// Stage A on the eight points of one lane.  In: R >= 8: v[m] = x[64 (u + Q m) + b];  R < 8: v[i R + a] = x[64 a + b_i].
+// Out: R >= 8: v[j] = Y_b[j + 8 u];  R < 8: v[i R + c] = Y_{b_i}[c]   (before the W_N^(b c) twiddle).
+template <int R, bool INV> __device__ __forceinline__ void stage_a(cf *v, const cf *tA, int u) {
+    constexpr int Q = Mid<R>::Q;
+    if (R == 1) return; // N = 64 (TX only): the symbol is a single row
+    if (R == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const cf a = v[2 * i], b = v[2 * i + 1]; v[2 * i] = cadd(a, b); v[2 * i + 1] = csub(a, b); }
+    } else if (R == 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            cf *x = v + 4 * i;
+            const cf s0 = cadd(x[0], x[2]), d0 = csub(x[0], x[2]), s1 = cadd(x[1], x[3]), d1 = mul_mj<INV>(csub(x[1], x[3]));
+            x[0] = cadd(s0, s1); x[2] = csub(s0, s1); x[1] = cadd(d0, d1); x[3] = csub(d0, d1);
+        }
+    } else {
+        bfly8<INV>(v);
+        if (Q > 1) {
+#pragma unroll
+            for (int j = 1; j < 8; ++j) v[j] = cmul(v[j], tA[j - 1]); // W_R^(u j)
+        }
+        if (Q == 2) { // radix-2 across the lane pair: Y_e = Z_0 + (-1)^e Z_1
+            const float sg = u ? -1.f : 1.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const cf o = dppq_cf<0xB1>(v[j]); // quad_perm [1,0,3,2]
+                v[j] = make_float2(fmaf(sg, v[j].x, o.x), fmaf(sg, v[j].y, o.y));
+            }
+        } else if (Q == 4) { // radix-4 across the quad: Y_e = (Z_0 + (-1)^e Z_2) + W4^e (Z_1 + (-1)^e Z_3)
+            const float s2 = (u & 1) ? -1.f : 1.f;
+            const float rx = u == 0 ? 1.f : (u == 2 ? -1.f : 0.f);
+            float ry = u == 1 ? -1.f : (u == 3 ? 1.f : 0.f);
+            if (INV) ry = -ry;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const cf z0 = dppq_cf<0x00>(v[j]), z1 = dppq_cf<0x55>(v[j]), z2 = dppq_cf<0xAA>(v[j]), z3 = dppq_cf<0xFF>(v[j]);
+                const cf pe = make_float2(fmaf(s2, z2.x, z0.x), fmaf(s2, z2.y, z0.y));
+                const cf po = make_float2(fmaf(s2, z3.x, z1.x), fmaf(s2, z3.y, z1.y));
+                v[j] = make_float2(fmaf(-ry, po.y, fmaf(rx, po.x, pe.x)), fmaf(ry, po.x, fmaf(rx, po.y, pe.y)));
+            }
+        }
+    }
+}
+
+// Stage B: FFT64 over the eight lanes of a row through the wave's XOR-swizzled slab (in: v[m] = Z[t + 8 m]; out: v[q] = X[t + 8 q])
+template <bool INV> __device__ __forceinline__ void stage_b(cf *v, cf *buf, int t, int wr, const cf *w) {
+    bfly8<INV>(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+    bfly8<INV>(v);
+}
+
+struct MidRxParams {
+    const float2 *in;
+    long long frame_stride;
+    long long total;          // symbols
+    int syms_per_frame, first_symbol;
+    long long step_f;         // frames / symbols one grid step advances
+    int step_k;
+    const float2 *tw;         // exp(-2 pi i m / N), m < N
+    const float2 *hk;         // optional channel, hk_stride = 0 (shared) or N (per frame)
+    long long hk_stride;
+    unsigned char *out;
+    long long out_stride;
+};
+
+template <int R, int BPS, bool GUARD>
+__global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p) {
+    typedef Mid<R> M;
+    constexpr int N = M::N, S = M::S, CP = M::CP, LPS = M::LPS, G = M::G, Q = M::Q, TS = M::TS;
+    constexpr int ND = GUARD ? 48 * R : N;
+    constexpr int IMG_DW = ND * BPS / 32;           // packed bytes of one symbol, in dwords
+    constexpr int nbytes = ND * BPS / 8;
+    __shared__ cf slab_all[4 * M::SLAB];            // [4 waves][8 x 72] FFT64 transpose slabs (stage B)
+    __shared__ cf T[32 * TS];                       // [G symbols x R row slots][72]
+    __shared__ unsigned img[G * IMG_DW];            // the symbols' packed output images
+    __shared__ float red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = tid / LPS, l = tid % LPS;
+    // stage A role
+    const int u = R >= 8 ? l % Q : 0;
+    const int colA = R >= 8 ? l / Q : l;            // R < 8: columns colA + LPS i, i < 8 / R
+    // stage B role
+    const int t = tid & 7, rs = tid >> 3;           // rs: row slot among the workgroup's 32
+    const int cB = M::row_of_slot(rs % R);
+    cf *buf = slab_all + wave * M::SLAB + (lane >> 3) * 72;
+    const int wr = swz(8 * t);
+
+    cf w[7];                                        // W64^(r t)
+#pragma unroll
+    for (int r = 1; r < 8; ++r) w[r - 1] = p.tw[R * r * t];
+    cf tA[7];                                       // W_R^(u j)
+#pragma unroll
+    for (int j = 1; j < 8; ++j) tA[j - 1] = Q > 1 ? p.tw[64 * u * j] : make_float2(1.f, 0.f);
+    cf z[8];                                        // W_N^(b c) of stage-A output e
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = R >= 8 ? p.tw[colA * (e + 8 * u)] : p.tw[(colA + LPS * (e / R)) * (e % R)];
+    int boff[8];                                    // bit offset of bin cB + R d (d = t + 8 q) in the image, -1 = not a data bin
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int d = t + 8 * q;
+        boff[q] = carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * R + cB) * BPS : -1;
+    }
+    unsigned *myimg = img + g * IMG_DW;
+
+    // (frame, symbol) of this lane's symbol, one step ahead (the prefetch) and now; advanced without divisions
+    long long fn; int kn;
+    {
+        const long long sg0 = (long long)blockIdx.x * G + g;
+        fn = sg0 / p.syms_per_frame; kn = (int)(sg0 - fn * p.syms_per_frame);
+    }
+    auto fetch = [&](long long sg, cf *dst) {
+        if (sg < p.total) {
+            const cf *src = p.in + fn * p.frame_stride + (long long)(p.first_symbol + kn) * S + CP + colA;
+            if (R >= 8) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) dst[m] = src[64 * (u + Q * m)];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[e] = src[64 * (e % R) + LPS * (e / R)];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) dst[m] = make_float2(0.f, 0.f);
+        }
+    };
+    // The image of step j leaves for HBM at the top of step j + 1, right after that step's samples have been taken out of
+    // the prefetch registers (loads and stores share the in-order VM counter; see k_demod4096).
+    auto flush = [&](unsigned *dst) {
+#pragma unroll
+        for (int i = l; i < IMG_DW; i += LPS) { dst[i] = myimg[i]; myimg[i] = 0u; }
+    };
+    for (int i = l; i < IMG_DW; i += LPS) myimg[i] = 0u;
+    cf pre[8];
+    fetch((long long)blockIdx.x * G + g, pre);
+    unsigned *pending = nullptr;
+    const long long stride = (long long)gridDim.x * G;
+
+    for (long long base = (long long)blockIdx.x * G; base < p.total; base += stride) {
+        const long long sg = base + g;
+        const long long f = fn; const int k = kn;
+        fn += p.step_f; kn += p.step_k;
+        if (kn >= p.syms_per_frame) { kn -= p.syms_per_frame; ++fn; }
+        cf v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = pre[m];
+        fetch(sg + stride, pre);
+        if (pending) flush(pending);
+        pending = sg < p.total ? reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes) : nullptr;
+        // ---- stage A, twiddle, transpose
+        stage_a<R, false>(v, tA, u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int slot = R >= 8 ? e * Q + u : e % R;
+            const int col = R >= 8 ? colA : colA + LPS * (e / R);
+            T[(g * R + slot) * TS + col] = (R < 8 && e % R == 0) ? v[e] : cmul(v[e], z[e]);
+        }
+        symbol_sync<LPS>(); // T complete
+        // ---- stage B: FFT64 over b for row cB
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = T[rs * TS + t + 8 * m];
+        stage_b<false>(v, buf, t, wr, w);
+        // v[q] = X[cB + R (t + 8 q)]
+        if (p.hk) { // equalise: Y /= H (src/receiver.rs:68-70)
+            const cf *h = p.hk + f * p.hk_stride;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const cf hh = h[cB + R * (t + 8 * q)];
+                const float rn = __builtin_amdgcn_rcpf(hh.x * hh.x + hh.y * hh.y);
+                const cf e = cmulc(v[q], hh);
+                v[q] = make_float2(e.x * rn, e.y * rn);
+            }
+        }
+        if (GUARD) { // decode_block (src/receiver.rs:106-145): mean angle of the 4 R pilots, rotate by -phase
+            // pilot classes 6, 25, 39, 58 = (t, q) = (6, 0), (1, 3), (7, 4), (2, 7); other lanes feed (1, 0) -> angle 0
+            cf pv = make_float2(1.f, 0.f);
+            pv = (t == 6) ? v[0] : pv;
+            pv = (t == 1) ? v[3] : pv;
+            pv = (t == 7) ? v[4] : pv;
+            pv = (t == 2) ? v[7] : pv;
+            float a = __ocml_atan2pi_f32(pv.y, pv.x);
+            constexpr int WL = LPS < 64 ? LPS : 64;
+#pragma unroll
+            for (int sh = WL / 2; sh >= 1; sh >>= 1) a += __shfl_xor(a, sh, 64);
+            if (LPS > 64) {
+                if (lane == 0) red[wave] = a;
+                __syncthreads();
+                a = 0.f;
+#pragma unroll
+                for (int i = 0; i < LPS / 64; ++i) a += red[g * (LPS / 64) + i];
+            }
+            const float trn = a * (0.5f / (4.0f * R)); // mean of the 4 R pilot angles, in turns -> hardware sin / cos
+            const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
+        }
+        // demodulate (src/receiver.rs:147-190) and pack LSB-first (src/utils.rs:30-36): OR every field into the image
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (boff[q] >= 0) {
+                const unsigned idx = demap_point(v[q], BPS);
+                const int wd = boff[q] >> 5, sh = boff[q] & 31;
+                atomicOr(&myimg[wd], idx << sh);
+                if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)
+                    if (sh + BPS > 32) atomicOr(&myimg[wd + 1], idx >> (32 - sh));
+                }
+            }
+        }
+        symbol_sync<LPS>(); // image complete; T / red are reused by the next step
+    }
+    if (pending) flush(pending);
+}
+
+// Persistent grid: OCC resident workgroups per CU (39 KB of LDS each).  OFDM_MID_GRID caps it (test hook: a small
+// grid makes every workgroup run many steps of the prefetch / deferred-store pipeline on a small batch).
+static long long mid_grid(long long steps, int num_cu, int occ) {
+    long long grid = (long long)num_cu * occ;
+    if (const char *e = getenv("OFDM_MID_GRID")) { const long long v = atoll(e); if (v > 0 && v < grid) grid = v; }
+    return grid > steps ? steps : grid;
+}
+
+template <int R, int BPS, bool GUARD> hipError_t launch_demod_mid(const MidRxParams &p0, hipStream_t st, int num_cu) {
+    MidRxParams p = p0;
+    constexpr int G = Mid<R>::G;
+    const long long steps = (p.total + G - 1) / G;
+    const long long grid = mid_grid(steps, num_cu, Mid<R>::OCC_RX);
+    const long long adv = grid * G;
+    p.step_f = adv / p.syms_per_frame;
+    p.step_k = (int)(adv - p.step_f * p.syms_per_frame);
+    hipLaunchKernelGGL((k_demod_mid<R, BPS, GUARD>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+template <int R> hipError_t dispatch_demod_mid(const MidRxParams &p, int bps, bool guard, hipStream_t st, int num_cu) {
+    switch (bps * 2 + (guard ? 1 : 0)) {
+    case 2: return launch_demod_mid<R, 1, false>(p, st, num_cu);
+    case 3: return launch_demod_mid<R, 1, true>(p, st, num_cu);
+    case 4: return launch_demod_mid<R, 2, false>(p, st, num_cu);
+    case 5: return launch_demod_mid<R, 2, true>(p, st, num_cu);
+    case 8: return launch_demod_mid<R, 4, false>(p, st, num_cu);
+    case 9: return launch_demod_mid<R, 4, true>(p, st, num_cu);
+    case 12: return launch_demod_mid<R, 6, false>(p, st, num_cu);
+    case 13: return launch_demod_mid<R, 6, true>(p, st, num_cu);
+    case 16: return launch_demod_mid<R, 8, false>(p, st, num_cu);
+    case 17: return launch_demod_mid<R, 8, true>(p, st, num_cu);
+    }
+    return hipErrorNotSupported;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_tx_mid: modulate + encode_block + prefix_block (src/transmitter.rs:108-181) for a continuous stream of N = 64 R
+// symbols, the mirror image of k_demod_mid:
+//     x[c + R d] = 1/N sum_b W64^(-b d) * [ W_N^(-b c) * sum_a X[64 a + b] W_R^(-a c) ]
+// Bin 64 a + b has carrier class class64((64 a + b) / R) and, among the data bins, ordinal dcb(class) R + b mod R.
+struct MidTxParams {
+    const uint8_t *bytes;
+    long long n_bytes, n_sym;
+    const float2 *tw;   // exp(-2 pi i m / N)
+    float2 *out;        // n_sym x (N + N/4) samples
+    int bps;
+};
+
+template <int R, bool GUARD>
+__global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
+    typedef Mid<R> M;
+    constexpr int N = M::N, S = M::S, CP = M::CP, LPS = M::LPS, G = M::G, Q = M::Q, TS = M::TS;
+    constexpr int ND = GUARD ? 48 * R : N;
+    constexpr int SB_DW = 16 * R + 2;               // a symbol's bytes as dwords (<= 64 R bytes) + slack for the two-byte window
+    __shared__ cf slab_all[4 * M::SLAB];
+    __shared__ __align__(16) cf T[32 * TS];
+    __shared__ unsigned sbw_all[G * SB_DW];
+    __shared__ float lvl[16];                       // axis levels by raw bit field (transmitter.rs:108-140)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = tid / LPS, l = tid % LPS;
+    const int u = R >= 8 ? l % Q : 0;
+    const int colA = R >= 8 ? l / Q : l;
+    const int t = tid & 7, rs = tid >> 3;
+    const int cB = M::row_of_slot(rs % R);
+    cf *buf = slab_all + wave * M::SLAB + (lane >> 3) * 72;
+    const int wr = swz(8 * t);
+    unsigned *sbw = sbw_all + g * SB_DW;
+    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
+    cf *Tsym = T + g * R * TS;
+
+    if (tid < 16) lvl[tid] = p.bps > 1 && tid < (1 << (p.bps >> 1)) ? axis_level((unsigned)tid, p.bps >> 1) : 0.f;
+    cf w[7];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { const cf x = p.tw[R * r * t]; w[r - 1] = make_float2(x.x, -x.y); }
+    cf tA[7];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) { const cf x = Q > 1 ? p.tw[64 * u * j] : make_float2(1.f, 0.f); tA[j - 1] = make_float2(x.x, -x.y); }
+    cf z[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const cf x = R >= 8 ? p.tw[colA * (e + 8 * u)] : p.tw[(colA + LPS * (e / R)) * (e % R)];
+        z[e] = make_float2(x.x, -x.y);
+    }
+    int boff[8]; // stage-A input e: bit offset of its bin inside the symbol's stream, -1 = null, -2 = pilot
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int a = R >= 8 ? u + Q * e : e % R;
+        const int b = R >= 8 ? colA : colA + LPS * (e / R);
+        const int bin = 64 * a + b, kc = bin / R, cls = carrier_class64(kc, GUARD);
+        boff[e] = cls == 0 ? (GUARD ? data_classes_below64(kc) * R + (b % R) : bin) * p.bps : (cls == 2 ? -2 : -1);
+    }
+    const int sym_bytes = ND * p.bps / 8;           // <= 64 R, a multiple of 4 (checked by the launcher)
+    const bool aligned = (reinterpret_cast<uintptr_t>(p.bytes) & 3) == 0;
+    auto dword = [&](long long by) -> unsigned {    // stream bytes by .. by + 3, zero past the end
+        if (aligned && by + 4 <= p.n_bytes) return *reinterpret_cast<const unsigned *>(p.bytes + by);
+        unsigned v = 0;
+        for (int j = 0; j < 4; ++j) if (by + j < p.n_bytes) v |= (unsigned)p.bytes[by + j] << (8 * j);
+        return v;
+    };
+    auto fetch = [&](long long sg, unsigned &d0, unsigned &d1) {
+        d0 = d1 = 0u;
+        if (sg >= p.n_sym) return;
+        const long long base = sg * sym_bytes;
+        if (4 * l < sym_bytes) d0 = dword(base + 4 * l);
+        if (4 * (l + LPS) < sym_bytes) d1 = dword(base + 4 * (l + LPS));
+    };
+    const long long stride = (long long)gridDim.x * G;
+    unsigned d0, d1;
+    fetch((long long)blockIdx.x * G + g, d0, d1);
+    sbw[l] = d0;
+    sbw[l + LPS] = d1;
+    if (l < 2) sbw[2 * LPS + l] = 0u;
+    fetch((long long)blockIdx.x * G + g + stride, d0, d1);
+    __syncthreads();
+
+    for (long long base = (long long)blockIdx.x * G; base < p.n_sym; base += stride) {
+        const long long sg = base + g;
+        long long left = p.n_bytes - sg * sym_bytes;              // stream bytes that belong to this symbol
+        left = left < 0 ? 0 : (left < sym_bytes ? left : sym_bytes);
+        const int live_bits = sg < p.n_sym ? (int)(((left * 8 + p.bps - 1) / p.bps) * p.bps) : 0;
+        cf v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cf pt = make_float2(0.f, 0.f);
+            if (boff[e] == -2) pt = make_float2(1.f, 0.f);
+            else if (boff[e] >= 0 && boff[e] < live_bits) {
+                const int bit = boff[e];
+                const unsigned two = (unsigned)sb[bit >> 3] | ((unsigned)sb[(bit >> 3) + 1] << 8);
+                const unsigned idx = (two >> (bit & 7)) & ((1u << p.bps) - 1u);
+                pt = p.bps == 1 ? map_point(idx, 1) : make_float2(lvl[idx & ((1u << (p.bps >> 1)) - 1u)], lvl[idx >> (p.bps >> 1)]);
+            }
+            v[e] = pt;
+        }
+        stage_a<R, true>(v, tA, u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int slot = R >= 8 ? e * Q + u : e % R;
+            const int col = R >= 8 ? colA : colA + LPS * (e / R);
+            Tsym[slot * TS + col] = (R < 8 && e % R == 0) ? v[e] : cmul(v[e], z[e]);
+        }
+        symbol_sync<LPS>(); // T complete; every lane of the symbol is past the mapping stage
+        sbw[l] = d0;        // next symbol's bytes
+        sbw[l + LPS] = d1;
+        fetch(sg + 2 * stride, d0, d1);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = T[rs * TS + t + 8 * m];
+        stage_b<true>(v, buf, t, wr, w);
+        // v[q] = N x[cB + R (t + 8 q)]: through T once more in sample order ([n >> 6][n & 63]) so that every store is a
+        // full 16 bytes per lane
+        symbol_sync<LPS>(); // every lane has read its stage-B inputs out of T
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = cB + R * (t + 8 * q);
+            Tsym[(n >> 6) * TS + (n & 63)] = make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N));
+        }
+        symbol_sync<LPS>();
+        if (sg < p.n_sym) { // prefix_block: out = [x[N - CP .. N), x[0 .. N)]
+            float4 *dst4 = reinterpret_cast<float4 *>(p.out + sg * S);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = l + LPS * j, n = 2 * i;                        // sample pair (n, n + 1)
+                const float4 y = *reinterpret_cast<const float4 *>(Tsym + (n >> 6) * TS + (n & 63));
+                dst4[(CP >> 1) + i] = y;
+                if (j == 3) dst4[i - ((N - CP) >> 1)] = y;                   // n >= N - CP: the cyclic prefix
+            }
+        }
+        symbol_sync<LPS>(); // sbw / T are reused by the next step
+    }
+}
+
+template <int R> hipError_t launch_tx_mid(const MidTxParams &p, bool guard, hipStream_t st, int num_cu) {
+    constexpr int G = Mid<R>::G;
+    const long long steps = (p.n_sym + G - 1) / G;
+    const long long grid = mid_grid(steps, num_cu, Mid<R>::OCC_TX);
+    if (guard) hipLaunchKernelGGL((k_tx_mid<R, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_tx_mid<R, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+} // namespace
+
+// RX demod of regular symbol streams for N in {128 .. 2048}.  hipErrorNotSupported => caller uses k_sym<N, M_DEMOD>.
+hipError_t run_demod_mid(int n_fft, const SymParams &sp, hipStream_t st, int num_cu) {
+    if (n_fft < 128 || n_fft > 2048) return hipErrorNotSupported;
+    if (sp.offset || sp.f_delta || sp.nsym_frame || sp.soft) return hipErrorNotSupported;
+    if (sp.syms_per_frame <= 0) return hipErrorNotSupported;
+    const int S = n_fft + n_fft / 4, R = n_fft / 64;
+    if ((long long)(sp.first_symbol + sp.syms_per_frame) * S > sp.frame_len) return hipErrorNotSupported; // no tail padding
+    if ((reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
+    if (sp.hk && sp.hk_stride != 0 && sp.hk_stride != n_fft) return hipErrorNotSupported;
+    MidRxParams p;
+    p.in = sp.in; p.frame_stride = sp.frame_stride; p.total = sp.n_frames * (long long)sp.syms_per_frame;
+    p.syms_per_frame = sp.syms_per_frame; p.first_symbol = sp.first_symbol; p.step_f = 0; p.step_k = 0;
+    p.tw = sp.tw; p.hk = sp.hk; p.hk_stride = sp.hk_stride; p.out = sp.out_bytes; p.out_stride = sp.out_stride;
+    if (p.total <= 0) return hipSuccess;
+    switch (R) {
+    case 2: return dispatch_demod_mid<2>(p, sp.bps, sp.guard != 0, st, num_cu);
+    case 4: return dispatch_demod_mid<4>(p, sp.bps, sp.guard != 0, st, num_cu);
+    case 8: return dispatch_demod_mid<8>(p, sp.bps, sp.guard != 0, st, num_cu);
+    case 16: return dispatch_demod_mid<16>(p, sp.bps, sp.guard != 0, st, num_cu);
+    case 32: return dispatch_demod_mid<32>(p, sp.bps, sp.guard != 0, st, num_cu);
+    }
+    return hipErrorNotSupported;
+}
+
+// Continuous-stream TX for N in {64 .. 2048} (N = 64: R = 1, stage A is the identity and 32 symbols share a workgroup step).
+// hipErrorNotSupported => caller uses k_sym<N, M_TX>.
+hipError_t run_tx_mid(int n_fft, const SymParams &sp, hipStream_t st, int num_cu) {
+    if (n_fft < 64 || n_fft > 2048) return hipErrorNotSupported;
+    if (sp.tx_raw_total < 0 || sp.syms_per_frame != 1 || sp.payload_len) return hipErrorNotSupported;
+    const int R = n_fft / 64, S = n_fft + n_fft / 4;
+    const int nd = sp.guard ? 48 * R : n_fft;
+    const int sym_bytes = nd * sp.bps / 8;
+    if ((sym_bytes & 3) || sp.payload_stride != sym_bytes || sp.out_stride_s != S) return hipErrorNotSupported;
+    if (reinterpret_cast<uintptr_t>(sp.out) & 15) return hipErrorNotSupported;
+    if (sp.n_frames <= 0) return hipSuccess;
+    MidTxParams p;
+    p.bytes = sp.payload; p.n_bytes = sp.tx_raw_total; p.n_sym = sp.n_frames; p.tw = sp.tw; p.out = sp.out; p.bps = sp.bps;
+    switch (R) {
+    case 1: return launch_tx_mid<1>(p, sp.guard != 0, st, num_cu);
+    case 2: return launch_tx_mid<2>(p, sp.guard != 0, st, num_cu);
+    case 4: return launch_tx_mid<4>(p, sp.guard != 0, st, num_cu);
+    case 8: return launch_tx_mid<8>(p, sp.guard != 0, st, num_cu);
+    case 16: return launch_tx_mid<16>(p, sp.guard != 0, st, num_cu);
+    case 32: return launch_tx_mid<32>(p, sp.guard != 0, st, num_cu);
+    }
+    return hipErrorNotSupported;
+}
+
+} // namespace ofdm

@@ -478,6 +478,12 @@ int ofdm_tx_symbols_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, of
         if (e == hipSuccess) return OFDM_OK;
         if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
+    if (c->prm.n_fft < 4096) { // R x 64 two-stage kernels (kernels_mid.hip; N = 64 is the one-row case)
+        static const bool off = getenv("OFDM_NO_MID_KERNELS") != nullptr;
+        hipError_t e = off ? hipErrorNotSupported : run_tx_mid(c->prm.n_fft, p, c->stream, c->num_cu);
+        if (e == hipSuccess) return OFDM_OK;
+        if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
+    }
     HIP_TRY(c, run_tx_symbols(c->prm.n_fft, p, c->stream, c->num_cu));
     return OFDM_OK;
 }
@@ -667,6 +673,12 @@ static int demod_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t fr
     if (c->prm.n_fft == 4096) { // 64 x 64 two-stage kernel for regular streams (kernels_fast.hip)
         static const bool off = getenv("OFDM_NO_DEMOD4096") != nullptr; // A/B switch
         hipError_t e = off ? hipErrorNotSupported : run_demod4096(p, c->stream, c->num_cu);
+        if (e == hipSuccess) return OFDM_OK;
+        if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
+    }
+    if (c->prm.n_fft > 64 && c->prm.n_fft < 4096) { // R x 64 two-stage kernels for regular streams (kernels_mid.hip)
+        static const bool off = getenv("OFDM_NO_MID_KERNELS") != nullptr; // A/B switch
+        hipError_t e = off ? hipErrorNotSupported : run_demod_mid(c->prm.n_fft, p, c->stream, c->num_cu);
         if (e == hipSuccess) return OFDM_OK;
         if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
