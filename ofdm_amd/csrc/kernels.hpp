@@ -69,6 +69,7 @@ hipError_t run_tx4096(const SymParams &p, hipStream_t st, int num_cu);
 // N = 128 .. 2048 symbol-stream fast paths (kernels_mid.hip); hipErrorNotSupported => generic k_sym
 hipError_t run_demod_mid(int n_fft, const SymParams &p, hipStream_t st, int num_cu);
 hipError_t run_tx_mid(int n_fft, const SymParams &p, hipStream_t st, int num_cu);
+hipError_t run_txframe_mid(int n_fft, const SymParams &p, const float2 *header, float header_max, hipStream_t st, int num_cu);
 // fused estimate_channel + per-symbol demod for N = 64 frames with per-frame offset / CFO / live-symbol count
 // final_out / final_stride / final_len (optional, 4-byte aligned): also do the length-header parse + truncate and write the
 // payload bytes to their final place (no outer code), so that no separate finish kernel is needed

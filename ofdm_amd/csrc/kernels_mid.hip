@@ -453,6 +453,204 @@ template <int R> hipError_t launch_tx_mid(const MidTxParams &p, bool guard, hipS
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_txframe_mid: encode (src/transmitter.rs:11-58) for N = 64 R, R in {2 .. 32}, in ONE pass over HBM: the data symbols of a
+// frame are built TWICE -- first only for the frame's signed maximum (normalize, transmitter.rs:184-188, needs it before
+// the first sample can leave), then again to be stored divided by it -- instead of written, read back and rewritten
+// (k_sym<N, M_TX> + k_tx_finish: three passes of 8 B per sample).  The inverse transform is the one of k_tx_mid.
+// A workgroup takes `fpw` whole frames per round (their D data symbols fill its 32 / R symbol slots step by step); the ten
+// constant header blocks are copied from the context's table, scaled like the rest.
+struct MidTxFrameParams {
+    const uint8_t *payload;
+    long long payload_stride;
+    const int32_t *payload_len;
+    int payload_bytes;
+    long long n_frames;
+    int D, fpw;          // data symbols per frame; frames per workgroup round (<= 32)
+    const float2 *tw;
+    const float2 *header; // 10 S samples
+    float header_max;
+    float2 *out;
+    long long out_stride; // samples
+    int bps;
+};
+
+template <int R, bool GUARD>
+__global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
+    typedef Mid<R> M;
+    constexpr int N = M::N, S = M::S, CP = M::CP, LPS = M::LPS, G = M::G, Q = M::Q, TS = M::TS;
+    constexpr int ND = GUARD ? 48 * R : N;
+    constexpr int SB_DW = 16 * R + 2;
+    __shared__ cf slab_all[4 * M::SLAB];
+    __shared__ __align__(16) cf T[32 * TS];
+    __shared__ unsigned sbw_all[G * SB_DW];
+    __shared__ float lvl[16];
+    __shared__ unsigned fmax[32];                   // per frame of the round: max(0, re, im) of its data symbols, as float bits
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = tid / LPS, l = tid % LPS;
+    const int u = R >= 8 ? l % Q : 0;
+    const int colA = R >= 8 ? l / Q : l;
+    const int t = tid & 7, rs = tid >> 3;
+    const int cB = M::row_of_slot(rs % R);
+    cf *buf = slab_all + wave * M::SLAB + (lane >> 3) * 72;
+    const int wr = swz(8 * t);
+    unsigned *sbw = sbw_all + g * SB_DW;
+    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
+    cf *Tsym = T + g * R * TS;
+
+    if (tid < 16) lvl[tid] = p.bps > 1 && tid < (1 << (p.bps >> 1)) ? axis_level((unsigned)tid, p.bps >> 1) : 0.f;
+    if (l < 2) sbw[2 * LPS + l] = 0u;               // slack for the two-byte window
+    cf w[7];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { const cf x = p.tw[R * r * t]; w[r - 1] = make_float2(x.x, -x.y); }
+    cf tA[7];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) { const cf x = Q > 1 ? p.tw[64 * u * j] : make_float2(1.f, 0.f); tA[j - 1] = make_float2(x.x, -x.y); }
+    cf z[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const cf x = R >= 8 ? p.tw[colA * (e + 8 * u)] : p.tw[(colA + LPS * (e / R)) * (e % R)];
+        z[e] = make_float2(x.x, -x.y);
+    }
+    int boff[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int a = R >= 8 ? u + Q * e : e % R;
+        const int b = R >= 8 ? colA : colA + LPS * (e / R);
+        const int bin = 64 * a + b, kc = bin / R, cls = carrier_class64(kc, GUARD);
+        boff[e] = cls == 0 ? (GUARD ? data_classes_below64(kc) * R + (b % R) : bin) * p.bps : (cls == 2 ? -2 : -1);
+    }
+    const int sym_bytes = ND * p.bps / 8;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.payload) | (uintptr_t)p.payload_stride) & 3) == 0;
+    // stream bytes by .. by + 3 of a frame: [16-byte little-endian length | payload | zeros] (src/packets/mod.rs:20-32)
+    auto dword = [&](const uint8_t *pay, long long len, long long by) -> unsigned {
+        if (by < 16) return by < 8 ? (unsigned)((unsigned long long)len >> (8 * by)) : 0u;
+        const long long off = by - 16;
+        if (aligned && off + 4 <= len) return *reinterpret_cast<const unsigned *>(pay + off);
+        unsigned v = 0;
+        for (int j = 0; j < 4; ++j) if (off + j < len) v |= (unsigned)pay[off + j] << (8 * j);
+        return v;
+    };
+    const int slots = p.fpw * p.D, steps = (slots + G - 1) / G;
+    const long long rounds = (p.n_frames + p.fpw - 1) / p.fpw;
+
+    // builds symbol (f, k): v[q] = N x[cB + R (t + 8 q)] (everything before the 1/N scale of k_tx_mid)
+    auto build = [&](bool valid, long long f, int k, cf *v) {
+        long long len = 0;
+        if (valid) {
+            len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+            const uint8_t *pay = p.payload + f * p.payload_stride;
+            const long long sb0 = (long long)k * sym_bytes;
+            sbw[l] = 4 * l < sym_bytes ? dword(pay, len, sb0 + 4 * l) : 0u;
+            sbw[l + LPS] = 4 * (l + LPS) < sym_bytes ? dword(pay, len, sb0 + 4 * (l + LPS)) : 0u;
+        }
+        symbol_sync<LPS>();
+        long long left = 16 + len - (long long)k * sym_bytes;   // stream bytes that belong to this symbol
+        left = left < 0 ? 0 : (left < sym_bytes ? left : sym_bytes);
+        const int live_bits = valid ? (int)(((left * 8 + p.bps - 1) / p.bps) * p.bps) : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cf pt = make_float2(0.f, 0.f);
+            if (boff[e] == -2) pt = make_float2(1.f, 0.f);
+            else if (boff[e] >= 0 && boff[e] < live_bits) {
+                const int bit = boff[e];
+                const unsigned two = (unsigned)sb[bit >> 3] | ((unsigned)sb[(bit >> 3) + 1] << 8);
+                const unsigned idx = (two >> (bit & 7)) & ((1u << p.bps) - 1u);
+                pt = p.bps == 1 ? map_point(idx, 1) : make_float2(lvl[idx & ((1u << (p.bps >> 1)) - 1u)], lvl[idx >> (p.bps >> 1)]);
+            }
+            v[e] = pt;
+        }
+        stage_a<R, true>(v, tA, u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int slot = R >= 8 ? e * Q + u : e % R;
+            const int col = R >= 8 ? colA : colA + LPS * (e / R);
+            Tsym[slot * TS + col] = (R < 8 && e % R == 0) ? v[e] : cmul(v[e], z[e]);
+        }
+        symbol_sync<LPS>();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = T[rs * TS + t + 8 * m];
+        stage_b<true>(v, buf, t, wr, w);
+        symbol_sync<LPS>(); // T and the byte window are free again
+    };
+
+    for (long long round = blockIdx.x; round < rounds; round += gridDim.x) {
+        if (tid < 32) fmax[tid] = 0u;
+        __syncthreads();
+        const long long f0 = round * p.fpw;
+        // ---- first build: the signed maximum of every frame of the round
+        for (int step = 0; step < steps; ++step) {
+            const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
+            const bool valid = sigma < slots && f0 + fl < p.n_frames;
+            cf v[8];
+            build(valid, f0 + fl, k, v);
+            float mine = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mine = fmaxf(mine, fmaxf(v[q].x, v[q].y) * (1.0f / N));
+            constexpr int WL = LPS < 64 ? LPS : 64;
+#pragma unroll
+            for (int sh = WL / 2; sh >= 1; sh >>= 1) mine = fmaxf(mine, __shfl_xor(mine, sh, 64));
+            if (valid && (l & (WL - 1)) == 0) atomicMax(&fmax[fl], __float_as_uint(mine));
+        }
+        __syncthreads();
+        // ---- header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
+        for (int fl = 0; fl < p.fpw && f0 + fl < p.n_frames; ++fl) {
+            const float mx = fmaxf(p.header_max, __uint_as_float(fmax[fl]));
+            float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride);
+            const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
+            for (int i = tid; i < 5 * S; i += 256) {
+                const float4 h = h4[i];
+                dst4[i] = make_float4(h.x / mx, h.y / mx, h.z / mx, h.w / mx);
+            }
+        }
+        // ---- second build: the samples, divided by the maximum
+        for (int step = 0; step < steps; ++step) {
+            const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
+            const bool valid = sigma < slots && f0 + fl < p.n_frames;
+            cf v[8];
+            build(valid, f0 + fl, k, v);
+            const float mx = fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int n = cB + R * (t + 8 * q);
+                Tsym[(n >> 6) * TS + (n & 63)] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
+            }
+            symbol_sync<LPS>();
+            if (valid) { // prefix_block: out = [x[N - CP .. N), x[0 .. N)]
+                float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride + (long long)(10 + k) * S);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = l + LPS * j, n = 2 * i;
+                    const float4 y = *reinterpret_cast<const float4 *>(Tsym + (n >> 6) * TS + (n & 63));
+                    dst4[(CP >> 1) + i] = y;
+                    if (j == 3) dst4[i - ((N - CP) >> 1)] = y;
+                }
+            }
+            symbol_sync<LPS>();
+        }
+        __syncthreads(); // fmax is reset by the next round
+    }
+}
+
+template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, hipStream_t st, int num_cu) {
+    constexpr int G = Mid<R>::G;
+    // frames per round: the count (<= 8, <= 32 slots' worth) that wastes the fewest symbol slots of the last step
+    int best = 1; double waste = 2.0;
+    for (int f = 1; f <= 8; ++f) {
+        const long long slots = (long long)f * p.D, padded = (slots + G - 1) / G * G;
+        const double wst = (double)(padded - slots) / (double)padded;
+        if (wst < waste - 1e-9) { waste = wst; best = f; }
+    }
+    p.fpw = best;
+    const long long rounds = (p.n_frames + p.fpw - 1) / p.fpw;
+    const long long grid = mid_grid(rounds, num_cu, 3); // built for 3 waves per SIMD: the twice-inlined symbol builder spills at 4
+    if (guard) hipLaunchKernelGGL((k_txframe_mid<R, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_txframe_mid<R, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 } // namespace
 
 // RX demod of regular symbol streams for N in {128 .. 2048}.  hipErrorNotSupported => caller uses k_sym<N, M_DEMOD>.
@@ -499,6 +697,27 @@ hipError_t run_tx_mid(int n_fft, const SymParams &sp, hipStream_t st, int num_cu
     case 8: return launch_tx_mid<8>(p, sp.guard != 0, st, num_cu);
     case 16: return launch_tx_mid<16>(p, sp.guard != 0, st, num_cu);
     case 32: return launch_tx_mid<32>(p, sp.guard != 0, st, num_cu);
+    }
+    return hipErrorNotSupported;
+}
+
+// encode for N in {128 .. 2048}: one pass over HBM.  hipErrorNotSupported => caller runs k_sym<N, M_TX> + k_tx_finish.
+hipError_t run_txframe_mid(int n_fft, const SymParams &sp, const float2 *header, float header_max, hipStream_t st, int num_cu) {
+    if (n_fft < 128 || n_fft > 2048) return hipErrorNotSupported;
+    if (sp.tx_raw_total >= 0 || sp.syms_per_frame <= 0) return hipErrorNotSupported;
+    const int R = n_fft / 64;
+    if ((reinterpret_cast<uintptr_t>(sp.out) & 15) || (sp.out_stride_s & 1)) return hipErrorNotSupported;
+    if (sp.n_frames <= 0) return hipSuccess;
+    MidTxFrameParams p;
+    p.payload = sp.payload; p.payload_stride = sp.payload_stride; p.payload_len = sp.payload_len; p.payload_bytes = sp.payload_bytes;
+    p.n_frames = sp.n_frames; p.D = sp.syms_per_frame; p.fpw = 1; p.tw = sp.tw; p.header = header; p.header_max = header_max;
+    p.out = sp.out; p.out_stride = sp.out_stride_s; p.bps = sp.bps;
+    switch (R) {
+    case 2: return launch_txframe_mid<2>(p, sp.guard != 0, st, num_cu);
+    case 4: return launch_txframe_mid<4>(p, sp.guard != 0, st, num_cu);
+    case 8: return launch_txframe_mid<8>(p, sp.guard != 0, st, num_cu);
+    case 16: return launch_txframe_mid<16>(p, sp.guard != 0, st, num_cu);
+    case 32: return launch_txframe_mid<32>(p, sp.guard != 0, st, num_cu);
     }
     return hipErrorNotSupported;
 }

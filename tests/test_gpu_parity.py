@@ -520,6 +520,32 @@ def test_tx_encode_batch(api, orc, n, mod, guard, nbytes, ecc):
         assert abs(max(frames[f].real.max(), frames[f].imag.max()) - 1.0) < 1e-6
 
 
+@pytest.mark.parametrize("n,mod,guard,nbytes", [(128, 6, True, 200), (128, 2, False, 3), (256, 4, True, 700), (512, 8, True, 2000),
+                                                 (512, 1, False, 100), (1024, 6, False, 2500), (2048, 4, True, 4000)])
+def test_tx_encode_mid_frames(api, orc, n, mod, guard, nbytes, monkeypatch):
+    """k_txframe_mid (encode in one HBM pass for N = 128 .. 2048: every frame built twice, once for its maximum) against the
+    oracle's encode, 11 frames with ragged payload lengths on a 2-workgroup grid (several rounds per workgroup, a last
+    round that is only partly filled).  src/transmitter.rs:11-58, 184-188."""
+    import torch
+    monkeypatch.setenv("OFDM_MID_GRID", "2")
+    rng = np.random.default_rng(n + mod + nbytes)
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    nfr = 11
+    lens = rng.integers(0, nbytes + 1, nfr).astype(np.int32)
+    lens[0], lens[-1] = nbytes, 0
+    pay = rng.integers(0, 256, (nfr, nbytes), dtype=np.uint8)
+    frames = host(ctx.encode_batch(torch.from_numpy(pay).to(ctx.device), lens=torch.from_numpy(lens)))
+    S, D = n + n // 4, ctx.data_symbols(nbytes)
+    assert frames.shape == (nfr, (10 + D) * S)
+    for f in range(nfr):
+        # up to its own last data symbol the frame equals the oracle's frame for that payload: the pilot-only symbols that
+        # fill the slot are below the frame maximum, so the normalisation is the same (as test_tx_encode_ragged_lengths)
+        want = orc.encode(bytes(pay[f, :lens[f]]), guard, mod, n)
+        assert rel_err(frames[f, :want.size], want) <= TOL, f"frame {f} (len {lens[f]})"
+        tail = frames[f, want.size:]
+        assert tail.size % S == 0 and (tail.size == 0 or np.abs(tail).max() <= np.abs(frames[f, :want.size]).max())
+        assert abs(max(frames[f].real.max(), frames[f].imag.max()) - 1.0) < 1e-6
+
 # ------------------------------------------------------------------ a10: decode (RX pipeline), config 3 shape
 def run_decode_parity(api, orc, n, mod, guard, ecc, nbytes, nfr, span_extra, seed, snr_db=30.0, cfo_abs=False):
     import torch

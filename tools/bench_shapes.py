@@ -43,6 +43,17 @@ def one(n_fft, mod, total, steps, k):
          "tx_ms": tx_ms, "tx_gsamples_per_s": n_sym * S / tx_ms / 1e6, "tx_frac": bytes_ / (tx_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
          "rx_ms": rx_ms, "rx_gsamples_per_s": n_sym * S / rx_ms / 1e6, "rx_frac": bytes_ / (rx_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
          "rx_bytes_equal_tx_payload": ok}
+    # frame-level TX (encode: header blocks + D data symbols, normalised per frame) and the staged chain behind OFDM_NO_MID_KERNELS
+    D = 16
+    nbytes = D * ctx.bytes_per_symbol - 16
+    fs = ctx.frame_samples(nbytes)
+    nfr = max(1, total // fs)
+    pay = torch.randint(0, 256, (nfr, nbytes), dtype=torch.uint8, device=ctx.device, generator=g)
+    fo = ctx.encode_batch(pay)
+    enc_ms = timed(lambda: ctx.encode_batch(pay, out=fo))
+    eb = nfr * (fs * 8 + nbytes)
+    r.update({"encode_frames": nfr, "encode_data_symbols": D, "encode_ms": enc_ms, "encode_gsamples_per_s": nfr * fs / enc_ms / 1e6,
+              "encode_frac": eb / (enc_ms / 1e3) / 1e9 / HBM_PEAK_GBS})
     ctx.close()
     return r
 
