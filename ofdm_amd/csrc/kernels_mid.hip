@@ -454,7 +454,7 @@ template <int R> hipError_t launch_tx_mid(const MidTxParams &p, bool guard, hipS
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_txframe_mid: encode (src/transmitter.rs:11-58) for N = 64 R, R in {2 .. 32}, in ONE pass over HBM: the data symbols of a
+// k_txframe_mid: encode (src/transmitter.rs:11-58) for N = 64 R, R in {1 .. 32}, in ONE pass over HBM: the data symbols of a
 // frame are built TWICE -- first only for the frame's signed maximum (normalize, transmitter.rs:184-188, needs it before
 // the first sample can leave), then again to be stored divided by it -- instead of written, read back and rewritten
 // (k_sym<N, M_TX> + k_tx_finish: three passes of 8 B per sample).  The inverse transform is the one of k_tx_mid.
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     auto dword = [&](const uint8_t *pay, long long len, long long by) -> unsigned {
         if (by < 16) return by < 8 ? (unsigned)((unsigned long long)len >> (8 * by)) : 0u;
         const long long off = by - 16;
-        if (aligned && off + 4 <= len) return *reinterpret_cast<const unsigned *>(pay + off);
+        if (aligned && (off & 3) == 0 && off + 4 <= len) return *reinterpret_cast<const unsigned *>(pay + off);
         unsigned v = 0;
         for (int j = 0; j < 4; ++j) if (off + j < len) v |= (unsigned)pay[off + j] << (8 * j);
         return v;
@@ -701,9 +701,10 @@ hipError_t run_tx_mid(int n_fft, const SymParams &sp, hipStream_t st, int num_cu
     return hipErrorNotSupported;
 }
 
-// encode for N in {128 .. 2048}: one pass over HBM.  hipErrorNotSupported => caller runs k_sym<N, M_TX> + k_tx_finish.
+// encode for N in {64 .. 2048}: one pass over HBM (N = 64: for the frames k_txframe64 does not take, more than 56 data
+// symbols).  hipErrorNotSupported => caller runs k_sym<N, M_TX> + k_tx_finish.
 hipError_t run_txframe_mid(int n_fft, const SymParams &sp, const float2 *header, float header_max, hipStream_t st, int num_cu) {
-    if (n_fft < 128 || n_fft > 2048) return hipErrorNotSupported;
+    if (n_fft < 64 || n_fft > 2048) return hipErrorNotSupported;
     if (sp.tx_raw_total >= 0 || sp.syms_per_frame <= 0) return hipErrorNotSupported;
     const int R = n_fft / 64;
     if ((reinterpret_cast<uintptr_t>(sp.out) & 15) || (sp.out_stride_s & 1)) return hipErrorNotSupported;
@@ -713,6 +714,7 @@ hipError_t run_txframe_mid(int n_fft, const SymParams &sp, const float2 *header,
     p.n_frames = sp.n_frames; p.D = sp.syms_per_frame; p.fpw = 1; p.tw = sp.tw; p.header = header; p.header_max = header_max;
     p.out = sp.out; p.out_stride = sp.out_stride_s; p.bps = sp.bps;
     switch (R) {
+    case 1: return launch_txframe_mid<1>(p, sp.guard != 0, st, num_cu);
     case 2: return launch_txframe_mid<2>(p, sp.guard != 0, st, num_cu);
     case 4: return launch_txframe_mid<4>(p, sp.guard != 0, st, num_cu);
     case 8: return launch_txframe_mid<8>(p, sp.guard != 0, st, num_cu);

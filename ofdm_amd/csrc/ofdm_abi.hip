@@ -733,7 +733,7 @@ int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, 
         if (fe == hipSuccess) return OFDM_OK;
         if (fe != hipErrorNotSupported) { c->last_hip = (int)fe; return OFDM_ERR_HIP; }
     }
-    if (c->prm.n_fft > 64 && c->prm.n_fft < 4096) { // R x 64 two-stage kernel, frames built twice: one pass over HBM (kernels_mid.hip)
+    if (c->prm.n_fft < 4096) { // R x 64 two-stage kernel, frames built twice: one pass over HBM (kernels_mid.hip)
         static const bool off = getenv("OFDM_NO_MID_KERNELS") != nullptr;
         hipError_t fe = off ? hipErrorNotSupported : run_txframe_mid(c->prm.n_fft, p, c->d_header, c->header_max, c->stream, c->num_cu);
         if (fe == hipSuccess) return OFDM_OK;
