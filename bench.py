@@ -303,6 +303,15 @@ def main():
                 import traceback
                 res[name] = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
             torch.cuda.empty_cache()
+        # every transform length the library accepts: symbol-stream TX / RX and frame-level encode against their one-pass
+        # rooflines (which lengths run shape-specialised kernels)
+        try:
+            shapes = __import__("tools.bench_shapes", fromlist=["one"])
+            res["shapes"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in shapes.one(n, 6, 1 << 25, 3, 8).items()}
+                             for n in (64, 128, 256, 512, 1024, 2048, 4096)]
+        except Exception as e:
+            res["shapes"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
 
     if rank == 0:
         print(json.dumps(res))
