@@ -3,6 +3,7 @@ hot kernels' 8-byte-per-lane access pattern (batched FFT: reads and writes n*512
 PACKET frames (the library's TX through its GPU channel model), at sizes beyond the 256 MiB Infinity Cache:
   cfg2  k_demod64                      cfg3  k_sc_cf + k_sc_post + k_rx_prepare + k_rxframe64, and the one-pass k_sc_cf<..,6,true>
   cfg4  Schmidl-Cox for L = 1280 + k_rxframe1024 + k_rx_finish        cfg5  k_tx4096, k_demod4096
+  mid   k_tx_mid, k_demod_mid, k_txframe_mid at N = 512 and 2048
 Prints the byte counts the summaries are divided by."""
 import json, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -59,4 +60,25 @@ for _ in range(2):
     c5.rx_demod(x5.view(1, -1), syms_per_frame=n5, out=out5)
 torch.cuda.synchronize()
 info.update(symbols_cfg5=n5, cfg5_sample_bytes=n5 * 5120 * 8, cfg5_payload_bytes=int(pay5.numel()))
+del x5, pay5, out5
+torch.cuda.empty_cache()
+# the R x 64 family (kernels_mid.hip): N = 512 (wave-local) and N = 2048 (barriers), 2^27 samples each: k_tx_mid, k_demod_mid,
+# and k_txframe_mid on 16-symbol frames
+for nn in (512, 2048):
+    cm = api.Context(n_fft=nn, modulation=api.QAM64, guard_bands=True)
+    ns = (1 << 27) // cm.S // 8 * 8
+    paym = torch.randint(0, 256, (ns * cm.bytes_per_symbol,), dtype=torch.uint8, device="cuda", generator=g)
+    outm = torch.empty((ns // 8, 8 * cm.bytes_per_symbol), dtype=torch.uint8, device="cuda")
+    nb = 16 * cm.bytes_per_symbol - 16
+    nfr = (1 << 27) // cm.frame_samples(nb)
+    payf = torch.randint(0, 256, (nfr, nb), dtype=torch.uint8, device="cuda", generator=g)
+    for _ in range(2):
+        xm = cm.tx_symbols(paym, ns)
+        cm.rx_demod(xm.view(ns // 8, 8 * cm.S), 8, out=outm)
+        fo = cm.encode_batch(payf)
+    torch.cuda.synchronize()
+    info[f"mid_{nn}"] = {"symbols": ns, "sample_bytes": ns * cm.S * 8, "payload_bytes": int(paym.numel()), "frames": nfr,
+                         "frame_bytes": nfr * cm.frame_samples(nb) * 8}
+    del xm, paym, outm, fo, payf
+    torch.cuda.empty_cache()
 print(json.dumps(info))
