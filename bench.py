@@ -307,7 +307,7 @@ def main():
         # rooflines (which lengths run shape-specialised kernels)
         try:
             shapes = __import__("tools.bench_shapes", fromlist=["one"])
-            res["shapes"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in shapes.one(n, 6, 1 << 25, 3, 8).items()}
+            res["shapes"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in shapes.one(n, 6, 1 << 27, 3, 8).items()}
                              for n in (64, 128, 256, 512, 1024, 2048, 4096)]
         except Exception as e:
             res["shapes"] = {"error": repr(e)}

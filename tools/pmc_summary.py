@@ -7,6 +7,7 @@ for path in sys.argv[1:]:
             name = row.get("Kernel_Name", "")
             if "ofdm::" not in name:
                 continue
+            name = name.replace("(anonymous namespace)::", "")   # kernels_mid.hip keeps its kernels in an unnamed namespace
             acc[name.split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in sorted(acc.items()):
     for c, vals in sorted(d.items()):
