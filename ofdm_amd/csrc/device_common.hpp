@@ -248,6 +248,30 @@ __device__ __forceinline__ cf map_point(unsigned idx, int bps) {
     const int m = bps >> 1;
     return make_float2(axis_level(idx & ((1u << m) - 1u), m), axis_level((idx >> m) & ((1u << m) - 1u), m));
 }
+// One constellation point of a TX symbol (src/transmitter.rs:108-165).  boff = bit offset of the bin's field inside the symbol's
+// byte window sbw (dwords, one slack dword behind it), -1 = null carrier, -2 = pilot; fields at or beyond live_bits carry no
+// stream bits (zero point, transmitter.rs:158-160); ptab[idx] = map_point(idx, bps) tabulated in LDS (bit-identical to the
+// staged modulate).  Two LDS instructions per point -- the two dwords that hold the field (one ds_read2_b32) and the point
+// (one ds_read_b64) -- instead of two byte reads and two axis-level reads: the mapping's LDS reads bound the TX kernels.
+// BRANCHFREE: dead lanes read dword 0 and discard it instead of branching around the reads (pays for k_tx4096, costs 30 % in
+// the R x 64 kernels, measured).
+template <bool BRANCHFREE>
+__device__ __forceinline__ cf tx_point(const unsigned *sbw, const cf *ptab, int boff, int live_bits, unsigned mask) {
+    const bool live = boff >= 0 && boff < live_bits;
+    const float px = boff == -2 ? 1.0f : 0.0f;
+    if (BRANCHFREE) {
+        const int bit = live ? boff : 0;
+        const unsigned lo = sbw[bit >> 5], hi = sbw[(bit >> 5) + 1];
+        const cf pt = ptab[__builtin_amdgcn_alignbit(hi, lo, (unsigned)bit & 31u) & mask];
+        return make_float2(live ? pt.x : px, live ? pt.y : 0.0f);
+    }
+    cf pt = make_float2(px, 0.0f);
+    if (live) {
+        const unsigned lo = sbw[boff >> 5], hi = sbw[(boff >> 5) + 1];
+        pt = ptab[__builtin_amdgcn_alignbit(hi, lo, (unsigned)boff & 31u) & mask];
+    }
+    return pt;
+}
 // bps bits starting at bit `bit` of an LSB-first byte stream made of a 16-byte little-endian length header
 // followed by payload[0..len)  (src/packets/mod.rs:20-32, src/transmitter.rs:37-47); bits past the end are 0
 __device__ __forceinline__ unsigned stream_byte(const uint8_t *__restrict__ payload, long long len, long long by) {

@@ -649,6 +649,8 @@ struct Big4096Params {
     long long frame_stride;
     long long total;          // symbols
     int syms_per_frame, first_symbol;
+    long long step_f;         // frames / symbols that one grid step (gridDim.x symbols) advances: no division in the loop
+    int step_k;
     const float2 *tw;         // exp(-2 pi i m / 4096), m < 4096
     const float2 *hk;         // optional channel, hk_stride = 0 (shared) or 4096 (per frame)
     long long hk_stride;
@@ -689,11 +691,13 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     }
     constexpr int nbytes = ND * BPS / 8;
 
+    // (frame, symbol) of the symbol one step ahead (the prefetch); advanced by the host's per-step increments -- the two 64-bit
+    // divisions per symbol this replaces were a third of the loop's instruction stream (408 of 1214, all scalar)
+    long long fn = blockIdx.x / p.syms_per_frame;
+    int kn = (int)(blockIdx.x - fn * p.syms_per_frame);
     auto fetch = [&](long long sg, cf *dst) {
         if (sg < p.total) {
-            const long long f = sg / p.syms_per_frame;
-            const int k = (int)(sg - f * p.syms_per_frame);
-            const cf *src = p.in + f * p.frame_stride + (long long)(p.first_symbol + k) * S + CP + col;
+            const cf *src = p.in + fn * p.frame_stride + (long long)(p.first_symbol + kn) * S + CP + col;
 #pragma unroll
             for (int m = 0; m < 8; ++m) dst[m] = src[64 * (t + 8 * m)];
         } else {
@@ -713,8 +717,10 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     unsigned *pending = nullptr; // where the image currently in LDS belongs
 
     for (long long sg = blockIdx.x; sg < p.total; sg += gridDim.x) {
-        const long long f = sg / p.syms_per_frame;
-        const int k = (int)(sg - f * p.syms_per_frame);
+        const long long f = fn;
+        const int k = kn;
+        fn += p.step_f; kn += p.step_k;
+        if (kn >= p.syms_per_frame) { kn -= p.syms_per_frame; ++fn; }
         cf v[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = pre[m];
@@ -829,6 +835,7 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64;
     long long grid = (long long)num_cu * 2;
     if (grid > p.total) grid = p.total;
+    p.step_f = grid / p.syms_per_frame; p.step_k = (int)(grid - p.step_f * p.syms_per_frame);
     // > 64 KB of dynamic LDS: a per-device attribute, so set on every call (one process may drive several GPUs); once per batch
 #define OFDM_LAUNCH_4096(B, G)                                                                                              \
     {                                                                                                                       \
@@ -1067,8 +1074,7 @@ __global__ __launch_bounds__(512, 4) void k_tx4096(Tx4096Params p) {
     cf *slab_all = reinterpret_cast<cf *>(smem);
     cf *T = slab_all + 8 * SLAB;
     unsigned *sbw = reinterpret_cast<unsigned *>(T + 64 * TS);          // [1024 + 2] the symbol's bytes as dwords
-    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
-    float *lvl = reinterpret_cast<float *>(sbw + 1024 + 4);             // [16] axis levels by raw bit field (transmitter.rs:108-140)
+    cf *ptab = reinterpret_cast<cf *>(sbw + 1024 + 4);                  // [256] map_point by raw bit field (transmitter.rs:108-140)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1076,7 +1082,8 @@ __global__ __launch_bounds__(512, 4) void k_tx4096(Tx4096Params p) {
     const int col = 8 * wave + s;
     cf *buf = slab_all + wave * SLAB + s * 72;
     const int wr = swz(8 * t);
-    if (tid < 16) lvl[tid] = p.bps > 1 && tid < (1 << (p.bps >> 1)) ? axis_level((unsigned)tid, p.bps >> 1) : 0.f;
+    if (tid < (1 << p.bps)) ptab[tid] = map_point((unsigned)tid, p.bps);
+    const unsigned fmask = (1u << p.bps) - 1u;
     cf w[7];
 #pragma unroll
     for (int r = 1; r < 8; ++r) { const cf x = p.tw[64 * r * t]; w[r - 1] = make_float2(x.x, -x.y); }
@@ -1119,21 +1126,13 @@ __global__ __launch_bounds__(512, 4) void k_tx4096(Tx4096Params p) {
     for (long long sg = blockIdx.x; sg < p.n_sym; sg += gridDim.x) {
         long long left = p.n_bytes - sg * sym_bytes;             // stream bytes that belong to this symbol
         left = left < 0 ? 0 : (left < sym_bytes ? left : sym_bytes);
-        const int live_bits = (int)(((left * 8 + p.bps - 1) / p.bps) * p.bps); // fields that carry stream bits; the rest are 0
+        const int live_bits = (int)(((unsigned)left * 8u + (unsigned)p.bps - 1u) / (unsigned)p.bps) * p.bps; // fields that carry stream bits (left <= 4096); the rest are 0
         cf v[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            cf pt = make_float2(0.f, 0.f);
-            if (boff[m] == -2) pt = make_float2(1.f, 0.f);
-            else if (boff[m] >= 0 && boff[m] < live_bits) {
-                const int bit = boff[m];
-                const unsigned two = (unsigned)sb[bit >> 3] | ((unsigned)sb[(bit >> 3) + 1] << 8);
-                const unsigned idx = (two >> (bit & 7)) & ((1u << p.bps) - 1u);
-                // constellation levels from a 16-entry LDS table filled with axis_level itself (bit-identical values): two
-                // reads per point instead of ~20 instructions of Gray decoding (round-2 ablation: 0.21 of 1.09 ms)
-                pt = p.bps == 1 ? map_point(idx, 1) : make_float2(lvl[idx & ((1u << (p.bps >> 1)) - 1u)], lvl[idx >> (p.bps >> 1)]);
-            }
-            v[m] = pt;
+            // constellation points from an LDS table filled with map_point itself (bit-identical values) instead of ~20
+            // instructions of Gray decoding per axis (round-2 ablation: 0.21 of 1.09 ms); branch-free
+            v[m] = tx_point<true>(sbw, ptab, boff[m], live_bits, fmask);
         }
         bfly8<true>(v);
 #pragma unroll
@@ -1189,7 +1188,7 @@ hipError_t run_tx4096(const SymParams &sp, hipStream_t st, int num_cu) {
     if (sp.n_frames <= 0) return hipSuccess;
     Tx4096Params p;
     p.bytes = sp.payload; p.n_bytes = sp.tx_raw_total; p.n_sym = sp.n_frames; p.tw = sp.tw; p.out = sp.out; p.bps = sp.bps; p.guard = sp.guard;
-    const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64 + 64;
+    const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 16 + 256 * sizeof(float2); // slabs, T, byte window + slack, point table
     {   // > 64 KB of dynamic LDS: per device, so set on every call (one process may drive several GPUs); once per batch
         hipError_t e = sp.guard ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_tx4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                                 : hipFuncSetAttribute(reinterpret_cast<const void *>(k_tx4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -341,10 +341,10 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
     cf *buf = slab_all + wave * M::SLAB + (lane >> 3) * 72;
     const int wr = swz(8 * t);
     unsigned *sbw = sbw_all + g * SB_DW;
-    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
     cf *Tsym = T + g * R * TS;
 
     if (tid < 16) lvl[tid] = p.bps > 1 && tid < (1 << (p.bps >> 1)) ? axis_level((unsigned)tid, p.bps >> 1) : 0.f;
+    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
     cf w[7];
 #pragma unroll
     for (int r = 1; r < 8; ++r) { const cf x = p.tw[R * r * t]; w[r - 1] = make_float2(x.x, -x.y); }
@@ -397,6 +397,9 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
         cf v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+            // two byte reads + two axis-level reads per point.  The dword + point-table mapping of k_txframe_mid / k_tx4096 (two LDS
+            // instructions instead of four) measured 10 % SLOWER in this kernel (0.238 -> 0.265 ms per 2^27 samples at N = 64 / 512), and
+            // the branch-free form 30 % slower: left as it was
             cf pt = make_float2(0.f, 0.f);
             if (boff[e] == -2) pt = make_float2(1.f, 0.f);
             else if (boff[e] >= 0 && boff[e] < live_bits) {
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     __shared__ cf slab_all[4 * M::SLAB];
     __shared__ __align__(16) cf T[32 * TS];
     __shared__ unsigned sbw_all[G * SB_DW];
-    __shared__ float lvl[16];
+    __shared__ cf ptab[256];
     __shared__ unsigned fmax[32];                   // per frame of the round: max(0, re, im) of its data symbols, as float bits
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -497,10 +500,10 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     cf *buf = slab_all + wave * M::SLAB + (lane >> 3) * 72;
     const int wr = swz(8 * t);
     unsigned *sbw = sbw_all + g * SB_DW;
-    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
     cf *Tsym = T + g * R * TS;
 
-    if (tid < 16) lvl[tid] = p.bps > 1 && tid < (1 << (p.bps >> 1)) ? axis_level((unsigned)tid, p.bps >> 1) : 0.f;
+    if (tid < (1 << p.bps)) ptab[tid] = map_point((unsigned)tid, p.bps);
+    const unsigned fmask = (1u << p.bps) - 1u;
     if (l < 2) sbw[2 * LPS + l] = 0u;               // slack for the two-byte window
     cf w[7];
 #pragma unroll
@@ -549,18 +552,10 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
         symbol_sync<LPS>();
         long long left = 16 + len - (long long)k * sym_bytes;   // stream bytes that belong to this symbol
         left = left < 0 ? 0 : (left < sym_bytes ? left : sym_bytes);
-        const int live_bits = valid ? (int)(((left * 8 + p.bps - 1) / p.bps) * p.bps) : 0;
+        const int live_bits = valid ? (int)(((unsigned)left * 8u + (unsigned)p.bps - 1u) / (unsigned)p.bps) * p.bps : 0; // left <= 2048
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            cf pt = make_float2(0.f, 0.f);
-            if (boff[e] == -2) pt = make_float2(1.f, 0.f);
-            else if (boff[e] >= 0 && boff[e] < live_bits) {
-                const int bit = boff[e];
-                const unsigned two = (unsigned)sb[bit >> 3] | ((unsigned)sb[(bit >> 3) + 1] << 8);
-                const unsigned idx = (two >> (bit & 7)) & ((1u << p.bps) - 1u);
-                pt = p.bps == 1 ? map_point(idx, 1) : make_float2(lvl[idx & ((1u << (p.bps >> 1)) - 1u)], lvl[idx >> (p.bps >> 1)]);
-            }
-            v[e] = pt;
+            v[e] = tx_point<false>(sbw, ptab, boff[e], live_bits, fmask);
         }
         stage_a<R, true>(v, tA, u);
 #pragma unroll
