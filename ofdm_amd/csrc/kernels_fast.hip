@@ -858,7 +858,7 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_rxframe1024: the per-frame RX body for N = 1024 after timing (BASELINE config 4), one 128-thread workgroup per
-// frame: estimate_channel on the 5 training blocks (1/H stays in registers), then every live data symbol: CFO
+// frame: estimate_channel on the 5 training blocks (summed in the time domain, ONE transform; 1/H stays in registers), then every live data symbol: CFO
 // derotation, CP strip + FFT1024, equalise, mean angle of the 64 pilots, hard demap, LSB-first packing.  The per-frame
 // scalars (offset, CFO, live symbols) are read once per frame and every symbol's samples are fetched while the previous
 // symbol is transformed.  The FFT is 16 x 64:
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(128, 2) void k_rxframe1024(RxFrame1024Params p) {
         cf pre[8];
         fetch(5, pre);
         unsigned *pending = nullptr; // where the image currently in LDS belongs
-        cf g[8]; // first the spectrum sum of the training blocks, then 1 / H
+        cf g[8]; // first the time-domain sum of the derotated training blocks, then 1 / H
 #pragma unroll
         for (int q = 0; q < 8; ++q) g[q] = make_float2(0.f, 0.f);
         // steps -5 .. -1: training blocks (chunks 5 .. 9); steps 0 .. ns-1: data symbols (chunks 10 ..)
@@ -950,6 +950,17 @@ __global__ __launch_bounds__(128, 2) void k_rxframe1024(RxFrame1024Params p) {
                 cf ph = cfo_phasor(turns, (long long)chunk * S + CP + 64 * u + b);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
+            }
+            if (k < 0) {
+                // estimate_channel (receiver.rs:212-229) averages the spectra of the 5 training blocks; the transform is linear, so
+                // the derotated blocks are summed in the time domain and transformed ONCE (as k_rxframe64 does): 5 transforms per
+                // frame instead of 9 for the 4-symbol frames of config 4.  (Measured: -10 % for this kernel, not -40 %: it waits for
+                // its loads, one memory round trip per block; issuing the training blocks' loads in batches spills ~40 registers.)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) g[m] = cadd(g[m], v[m]);
+                if (k < -1) continue; // workgroup-uniform; no barrier has been passed in this step
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = g[m];
             }
             // ---- stage A: FFT16 over a = u + 2 m  (8-point butterfly, then radix 2 across the lane pair)
             bfly8<false>(v);
@@ -973,19 +984,15 @@ __global__ __launch_bounds__(128, 2) void k_rxframe1024(RxFrame1024Params p) {
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w64tab[(r - 1) * 8 + t]);
             bfly8<false>(v);
             // v[q] = X[row + 16 (t + 8 q)]
-            if (k < 0) { // estimate_channel (receiver.rs:212-229): H = mean_b FFT(block_b) / training
+            if (k < 0) { // k == -1: H = FFT(sum of the training blocks) / 5 / training
 #pragma unroll
-                for (int q = 0; q < 8; ++q) g[q] = cadd(g[q], v[q]);
-                if (k == -1) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int bin = row + 16 * (t + 8 * q);
-                        cf h = cmul(g[q], p.inv_training[bin]);
-                        h = make_float2(h.x * 0.2f, h.y * 0.2f);
-                        if (p.hk) p.hk[f * N + bin] = h;
-                        const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
-                        g[q] = make_float2(h.x * rn, -h.y * rn); // 1 / H
-                    }
+                for (int q = 0; q < 8; ++q) {
+                    const int bin = row + 16 * (t + 8 * q);
+                    cf h = cmul(v[q], p.inv_training[bin]);
+                    h = make_float2(h.x * 0.2f, h.y * 0.2f);
+                    if (p.hk) p.hk[f * N + bin] = h;
+                    const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
+                    g[q] = make_float2(h.x * rn, -h.y * rn); // 1 / H
                 }
                 __syncthreads(); // T is rewritten by the next symbol
                 continue;

@@ -153,11 +153,12 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
 #pragma unroll
                     for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
                 }
-                fft_symbol<N, false>(v, buf, t, w);
+                // the transform is linear: the derotated blocks are summed in the time domain and transformed once
 #pragma unroll
                 for (int m = 0; m < 8; ++m) acc[m] = cadd(acc[m], v[m]);
-                group_sync<T>();
             }
+            fft_symbol<N, false>(acc, buf, t, w);
+            group_sync<T>();
             if (valid) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
