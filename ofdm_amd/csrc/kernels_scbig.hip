@@ -15,8 +15,9 @@
 //                      |P(d)| <= |P0| + 1/2 (Te[c] + Te[c+L] + Te[c+W] + Te[c+W+L]),  E(d) >= E0 - Te[c],  R(d) >= R0 - Te[c+L],
 //                  so only chunks whose bound reaches the threshold are searched for the first crossing d1, and only chunks
 //                  whose bound reaches the best exact value found so far are searched for the peak over [d1, d1 + W].
-//                  A search evaluates a tile of 1280 lags exactly: four 1280-sample segments (at d0, d0+L, d0+W, d0+W+L) are
-//                  staged into LDS, each thread slides the three sums over its 10 lags in f64 from the tile's boundary sums
+//                  A search evaluates a tile of 320 (N <= 2048) or 640 lags exactly: four segments of that many samples (at d0,
+//                  d0+L, d0+W, d0+W+L) are staged into LDS, each thread slides the three sums over its 5 / 10 lags in f64 from the
+//                  tile's boundary sums
 //                  (prefix differences), a workgroup scan chains the threads.
 // Every decision is taken on f64 sums, as k_sc_tile does: timing indices equal the f64 oracle's except on ties below f64
 // resolution.  Works for any N in 128..4096 (the LDS footprint does not depend on L) and any capture of up to 2047 chunks.
@@ -29,8 +30,9 @@ namespace ofdm {
 namespace {
 
 constexpr int B_TILE = 2560;   // samples per chunk-sum tile (256 threads x 10)
-constexpr int F_WG = 64;        // one wavefront per frame: 20 KB of LDS, 7 frames in flight per CU (128 threads / 1280 lags: 3 per CU, 25 % slower)
-constexpr int F_TILE = 10 * F_WG; // lags per fine tile
+constexpr int F_WG = 64;        // one wavefront per frame; tiles of 5 or 10 lags per thread (run_sc_big): 11 / 21 KB of LDS, 12 / 7 frames
+                                // in flight per CU (128 threads / 1280 lags: 3 per CU, 25 % slower)
+constexpr int F_TILE_MAX = 10 * F_WG; // lags per fine tile (k_scb_fine<10>; <5> halves it: see run_sc_big)
 
 struct BSums { double pr, pi, e, r; };
 __device__ __forceinline__ BSums bs_add(BSums a, BSums b) { return BSums{a.pr + b.pr, a.pi + b.pi, a.e + b.e, a.r + b.r}; }
@@ -151,7 +153,9 @@ __global__ __launch_bounds__(256) void k_scb_chunks(ScBigParams p) {
 }
 
 // ---- prefix sums, chunk bounds, first crossing, peak
-__global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
+template <int LPT>
+__global__ __launch_bounds__(F_WG, LPT == 10 ? 2 : 3) void k_scb_fine(ScBigParams p) {
+    constexpr int F_TILE = LPT * F_WG;   // lags per fine tile
     extern __shared__ __align__(16) unsigned char smem[];
     cf *s0 = reinterpret_cast<cf *>(smem);       // [F_TILE + 16] samples at d0 ..
     cf *s1 = s0 + F_TILE + 16;                   // ... at d0 + L
@@ -217,15 +221,29 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
             {
                 cf *const dsts[4] = {s0, s1, s2, s3};
                 const long long firsts[4] = {d0, d0 + L, d0 + W, d0 + W + L};
-                stage_segments<4, F_TILE / 2 / F_WG>(dsts, frame, firsts, p.frame_len, tid, F_WG);
+                if (LPT % 2 == 0) stage_segments<4, (LPT % 2 == 0 ? LPT / 2 : 1)>(dsts, frame, firsts, p.frame_len, tid, F_WG);
+                else { // odd lags per thread: 8-byte loads, all issued before the first LDS store
+                    cf x[4][LPT];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int j = 0; j < LPT; ++j) {
+                            const long long n = firsts[g] + tid + j * F_WG;
+                            x[g][j] = n < p.frame_len ? frame[n] : make_float2(0.f, 0.f);
+                        }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int j = 0; j < LPT; ++j) dsts[g][tid + j * F_WG] = x[g][j];
+                }
             }
             __syncthreads();
-            const int a0 = tid * 10;
-            BSums pre[10];
+            const int a0 = tid * LPT;
+            BSums pre[LPT];
             {
                 BSums run = BSums{0, 0, 0, 0};
 #pragma unroll
-                for (int j = 0; j < 10; ++j) {
+                for (int j = 0; j < LPT; ++j) {
                     const cf x0 = s0[a0 + j], x1 = s1[a0 + j], x2 = s2[a0 + j], x3 = s3[a0 + j];
                     const double r0 = x0.x, i0 = x0.y, r1 = x1.x, i1 = x1.y, r2 = x2.x, i2 = x2.y, r3 = x3.x, i3 = x3.y;
                     run.pr += (r2 * r3 + i2 * i3) - (r0 * r1 + i0 * i1);
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
                     pre[j] = run;
                 }
             }
-            BSums inc = pre[9];
+            BSums inc = pre[LPT - 1];
 #pragma unroll
             for (int sft = 1; sft < 64; sft <<= 1) {
                 const BSums o = BSums{__shfl_up(inc.pr, sft, 64), __shfl_up(inc.pi, sft, 64), __shfl_up(inc.e, sft, 64), __shfl_up(inc.r, sft, 64)};
@@ -254,7 +272,7 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
             if (want_cross) {
                 int mine = INT_MAX;
 #pragma unroll
-                for (int j = 9; j >= 0; --j) {
+                for (int j = LPT - 1; j >= 0; --j) {
                     const BSums x = j ? bs_add(base, pre[j - 1]) : base;
                     const double num = x.pr * x.pr + x.pi * x.pi, den = x.e * x.r;
                     const long long lag = d0 + a0 + j;
@@ -272,7 +290,7 @@ __global__ __launch_bounds__(F_WG) void k_scb_fine(ScBigParams p) {
             }
             BCand mineb = BCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
 #pragma unroll
-            for (int j = 0; j < 10; ++j) {
+            for (int j = 0; j < LPT; ++j) {
                 const BSums x = j ? bs_add(base, pre[j - 1]) : base;
                 const double num = x.pr * x.pr + x.pi * x.pi, den = x.e * x.r;
                 const long long lag = d0 + a0 + j;
@@ -386,17 +404,20 @@ hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_
     } else hipLaunchKernelGGL(k_scb_chunks<false>, dim3((unsigned)g1), dim3(256), lds1, st, q);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const size_t lds = (size_t)4 * (F_TILE + 16) * sizeof(float2) + (size_t)q.nch_pad * sizeof(float) + 2 * sizeof(BSums) +
+    // Tiles start at chunk boundaries, so a tile is a whole number of chunks: 320-lag tiles (5 lags per thread) where C <= 320
+    // (N <= 2048), 640-lag tiles for N = 4096.  The small tile halves the LDS and the registers of a frame (12 instead of 7
+    // frames in flight per CU) at twice the number of tiles.
+    const bool small = q.C <= 320 && (320 % q.C) == 0 && getenv("OFDM_SCB_BIG_TILES") == nullptr;
+    const int f_tile = small ? 5 * F_WG : 10 * F_WG;
+    const size_t lds = (size_t)4 * (f_tile + 16) * sizeof(float2) + (size_t)q.nch_pad * sizeof(float) + 2 * sizeof(BSums) +
                        2 * sizeof(BCand) + 4 * sizeof(int) + 64;
-    if (lds > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scb_fine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
-    if (per_cu > 8) per_cu = 8;
+    const long long cap = small ? 12 : 8; // 3 / 2 waves per SIMD (163 / 236 VGPRs; 4 waves spill 22 registers for +2 %)
+    if (per_cu > cap) per_cu = cap;
     long long g2 = (long long)num_cu * per_cu;
     if (g2 > p.n_frames) g2 = p.n_frames;
-    hipLaunchKernelGGL(k_scb_fine, dim3((unsigned)g2), dim3(F_WG), lds, st, q);
+    if (small) hipLaunchKernelGGL(k_scb_fine<5>, dim3((unsigned)g2), dim3(F_WG), lds, st, q);
+    else hipLaunchKernelGGL(k_scb_fine<10>, dim3((unsigned)g2), dim3(F_WG), lds, st, q);
     return hipGetLastError();
 }
 
