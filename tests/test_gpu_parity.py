@@ -718,6 +718,28 @@ def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod,
 
 
 # ------------------------------------------------------------------ EXT-3 for long periods (kernels_scbig.hip), EXT-4 decode up to N = 4096
+def test_long_period_fine_tiles_agree(api, monkeypatch):
+    """k_scb_fine<5> (320-lag tiles, the default for N <= 2048) and k_scb_fine<10> (640-lag tiles, OFDM_SCB_BIG_TILES=1) walk the
+    same exact sums in different tile sizes: identical timing index, CFO to 1e-12 and metric to 1e-6 on 96 N = 1024 captures from the library's
+    TX and GPU channel (each tiling is compared with the oracle in test_sc_correlate_and_decode_long_periods)."""
+    import math
+    import torch
+    ctx = api.Context(n_fft=1024, modulation=api.QAM16, guard_bands=True)
+    g = torch.Generator(device=ctx.device); g.manual_seed(5)
+    nfr = 96
+    pay = torch.randint(0, 256, (nfr, 700), dtype=torch.uint8, device=ctx.device, generator=g)
+    tx = ctx.encode_batch(pay)
+    d = torch.randint(1, 1281, (nfr,), device=ctx.device, generator=g, dtype=torch.int32)
+    fd = (torch.rand((nfr,), device=ctx.device, generator=g, dtype=torch.float64) * 1.8 - 0.9) * math.pi / ctx.S
+    x = ctx.channel_batch(tx, snr_db=35.0, seed=9, delay=d, f_delta=fd, span=tx.shape[1] + 1536)
+    small = [host(v) for v in ctx.sc_correlate(x)]
+    monkeypatch.setenv("OFDM_SCB_BIG_TILES", "1")
+    big = [host(v) for v in ctx.sc_correlate(x)]
+    assert (small[0] >= 0).all() and np.array_equal(small[0], big[0])
+    # the f64 sums are accumulated in a different order: equal to rounding, not to the bit
+    assert np.abs(small[1] - big[1]).max() <= 1e-12 and np.abs(small[2] - big[2]).max() <= 1e-6
+
+
 @pytest.mark.parametrize("n,mod,nbytes", [(128, 4, 300), (256, 6, 700), (512, 2, 500), (1024, 6, 1304), (2048, 4, 3000), (4096, 8, 9000)])
 def test_sc_correlate_and_decode_long_periods(api, orc, n, mod, nbytes):
     """Schmidl-Cox for L = 160 .. 5120 (chunk sums + bounded exact search) against the oracle over ALL lags of the capture
