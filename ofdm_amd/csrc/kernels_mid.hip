@@ -575,55 +575,56 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
         if (tid < 32) fmax[tid] = 0u;
         __syncthreads();
         const long long f0 = round * p.fpw;
-        // ---- first build: the signed maximum of every frame of the round
-        for (int step = 0; step < steps; ++step) {
-            const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
-            const bool valid = sigma < slots && f0 + fl < p.n_frames;
-            cf v[8];
-            build(valid, f0 + fl, k, v);
-            float mine = 0.f;
+        // pass 0: the signed maximum of every frame of the round; pass 1: the samples, divided by it.  ONE instance of the symbol
+        // builder, the pass is a uniform branch around its two epilogues (two inlined instances spill at 4 waves per SIMD).
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int step = 0; step < steps; ++step) {
+                const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
+                const bool valid = sigma < slots && f0 + fl < p.n_frames;
+                cf v[8];
+                build(valid, f0 + fl, k, v);
+                if (pass == 0) {
+                    float mine = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) mine = fmaxf(mine, fmaxf(v[q].x, v[q].y) * (1.0f / N));
-            constexpr int WL = LPS < 64 ? LPS : 64;
+                    for (int q = 0; q < 8; ++q) mine = fmaxf(mine, fmaxf(v[q].x, v[q].y) * (1.0f / N));
+                    constexpr int WL = LPS < 64 ? LPS : 64;
 #pragma unroll
-            for (int sh = WL / 2; sh >= 1; sh >>= 1) mine = fmaxf(mine, __shfl_xor(mine, sh, 64));
-            if (valid && (l & (WL - 1)) == 0) atomicMax(&fmax[fl], __float_as_uint(mine));
-        }
-        __syncthreads();
-        // ---- header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
-        for (int fl = 0; fl < p.fpw && f0 + fl < p.n_frames; ++fl) {
-            const float mx = fmaxf(p.header_max, __uint_as_float(fmax[fl]));
-            float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride);
-            const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
-            for (int i = tid; i < 5 * S; i += 256) {
-                const float4 h = h4[i];
-                dst4[i] = make_float4(h.x / mx, h.y / mx, h.z / mx, h.w / mx);
+                    for (int sh = WL / 2; sh >= 1; sh >>= 1) mine = fmaxf(mine, __shfl_xor(mine, sh, 64));
+                    if (valid && (l & (WL - 1)) == 0) atomicMax(&fmax[fl], __float_as_uint(mine));
+                    continue;
+                }
+                const float mx = fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int n = cB + R * (t + 8 * q);
+                    Tsym[(n >> 6) * TS + (n & 63)] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
+                }
+                symbol_sync<LPS>();
+                if (valid) { // prefix_block: out = [x[N - CP .. N), x[0 .. N)]
+                    float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride + (long long)(10 + k) * S);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = l + LPS * j, n = 2 * i;
+                        const float4 y = *reinterpret_cast<const float4 *>(Tsym + (n >> 6) * TS + (n & 63));
+                        dst4[(CP >> 1) + i] = y;
+                        if (j == 3) dst4[i - ((N - CP) >> 1)] = y;
+                    }
+                }
+                symbol_sync<LPS>();
             }
-        }
-        // ---- second build: the samples, divided by the maximum
-        for (int step = 0; step < steps; ++step) {
-            const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
-            const bool valid = sigma < slots && f0 + fl < p.n_frames;
-            cf v[8];
-            build(valid, f0 + fl, k, v);
-            const float mx = fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int n = cB + R * (t + 8 * q);
-                Tsym[(n >> 6) * TS + (n & 63)] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
-            }
-            symbol_sync<LPS>();
-            if (valid) { // prefix_block: out = [x[N - CP .. N), x[0 .. N)]
-                float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride + (long long)(10 + k) * S);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = l + LPS * j, n = 2 * i;
-                    const float4 y = *reinterpret_cast<const float4 *>(Tsym + (n >> 6) * TS + (n & 63));
-                    dst4[(CP >> 1) + i] = y;
-                    if (j == 3) dst4[i - ((N - CP) >> 1)] = y;
+            if (pass == 0) {
+                __syncthreads();
+                // ---- header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
+                for (int fl = 0; fl < p.fpw && f0 + fl < p.n_frames; ++fl) {
+                    const float mx = fmaxf(p.header_max, __uint_as_float(fmax[fl]));
+                    float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride);
+                    const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
+                    for (int i = tid; i < 5 * S; i += 256) {
+                        const float4 h = h4[i];
+                        dst4[i] = make_float4(h.x / mx, h.y / mx, h.z / mx, h.w / mx);
+                    }
                 }
             }
-            symbol_sync<LPS>();
         }
         __syncthreads(); // fmax is reset by the next round
     }
