@@ -66,6 +66,7 @@ hipError_t run_demod4096(const SymParams &p, hipStream_t st, int num_cu);
 hipError_t run_rxframe1024(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu);
 // N = 4096 continuous-stream TX (map + IFFT + CP) as 64 x 64; needs tx_raw_total >= 0
 hipError_t run_tx4096(const SymParams &p, hipStream_t st, int num_cu);
+hipError_t run_txframe4096(const SymParams &p, const float2 *header, float header_max, hipStream_t st, int num_cu);
 // N = 128 .. 2048 symbol-stream fast paths (kernels_mid.hip); hipErrorNotSupported => generic k_sym
 hipError_t run_demod_mid(int n_fft, const SymParams &p, hipStream_t st, int num_cu);
 hipError_t run_tx_mid(int n_fft, const SymParams &p, hipStream_t st, int num_cu);

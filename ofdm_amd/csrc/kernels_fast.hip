@@ -1208,6 +1208,176 @@ hipError_t run_tx4096(const SymParams &sp, hipStream_t st, int num_cu) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_txframe4096: encode (src/transmitter.rs:11-58) for N = 4096 in ONE pass over HBM, the frame-level sibling of k_tx4096 and
+// the R = 64 member of k_txframe_mid's scheme (kernels_mid.hip): one 512-thread workgroup per frame builds the frame's data
+// symbols TWICE -- pass 0 only for the signed maximum normalize needs (transmitter.rs:184-188), pass 1 to store them divided
+// by it -- instead of writing, reading back and rewriting them (k_sym<4096, M_TX> + k_tx_finish: 24 B of traffic per sample).
+// One instance of the symbol builder, the pass is a uniform branch around the two epilogues.
+struct TxFrame4096Params {
+    const uint8_t *payload;
+    long long payload_stride;
+    const int32_t *payload_len;
+    int payload_bytes;
+    long long n_frames;
+    int D;               // data symbols per frame
+    const float2 *tw;    // exp(-2 pi i m / 4096)
+    const float2 *header; // 10 S samples
+    float header_max;
+    float2 *out;
+    long long out_stride; // samples
+    int bps;
+};
+
+template <bool GUARD>
+__global__ __launch_bounds__(512, 4) void k_txframe4096(TxFrame4096Params p) {
+    constexpr int N = 4096, S = 5120, CP = 1024, TS = 72, SLAB = 8 * 72;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf *slab_all = reinterpret_cast<cf *>(smem);
+    cf *T = slab_all + 8 * SLAB;
+    unsigned *sbw = reinterpret_cast<unsigned *>(T + 64 * TS);          // [1024 + 4] the symbol's bytes as dwords + slack
+    cf *ptab = reinterpret_cast<cf *>(sbw + 1024 + 4);                  // [256] map_point by raw bit field
+    unsigned *fmax = reinterpret_cast<unsigned *>(ptab + 256);          // [1] max(0, re, im) of the frame's data symbols, float bits
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane >> 3, t = lane & 7;
+    const int col = 8 * wave + s;
+    cf *buf = slab_all + wave * SLAB + s * 72;
+    const int wr = swz(8 * t);
+    if (tid < (1 << p.bps)) ptab[tid] = map_point((unsigned)tid, p.bps);
+    if (tid < 4) sbw[1024 + tid] = 0u;
+    const unsigned fmask = (1u << p.bps) - 1u;
+    cf w[7];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { const cf x = p.tw[64 * r * t]; w[r - 1] = make_float2(x.x, -x.y); }
+    cf z[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const cf x = p.tw[col * (t + 8 * q)]; z[q] = make_float2(x.x, -x.y); }
+    int boff[8]; // bit offset of bin 64 (t + 8 m) + col inside the symbol's stream, -1 = null, -2 = pilot
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int a = t + 8 * m, cls = carrier_class64(a, GUARD);
+        boff[m] = cls == 0 ? ((GUARD ? data_classes_below64(a) : a) * 64 + col) * p.bps : (cls == 2 ? -2 : -1);
+    }
+    const int nd = GUARD ? 48 * 64 : N;
+    const int sym_bytes = nd * p.bps / 8;   // <= 4096, a multiple of 4
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.payload) | (uintptr_t)p.payload_stride) & 3) == 0;
+    // stream bytes by .. by + 3 of a frame: [16-byte little-endian length | payload | zeros] (src/packets/mod.rs:20-32)
+    auto dword = [&](const uint8_t *pay, long long len, long long by) -> unsigned {
+        if (by < 16) return by < 8 ? (unsigned)((unsigned long long)len >> (8 * by)) : 0u;
+        const long long off = by - 16;
+        if (aligned && (off & 3) == 0 && off + 4 <= len) return *reinterpret_cast<const unsigned *>(pay + off);
+        unsigned v = 0;
+        for (int j = 0; j < 4; ++j) if (off + j < len) v |= (unsigned)pay[off + j] << (8 * j);
+        return v;
+    };
+
+    for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+        if (tid == 0) *fmax = 0u;
+        const long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+        const uint8_t *pay = p.payload + f * p.payload_stride;
+        cf *row = p.out + f * p.out_stride;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int k = 0; k < p.D; ++k) {
+                const long long sb0 = (long long)k * sym_bytes;
+                sbw[tid] = 4 * tid < sym_bytes ? dword(pay, len, sb0 + 4 * tid) : 0u;
+                sbw[tid + 512] = 4 * (tid + 512) < sym_bytes ? dword(pay, len, sb0 + 4 * (tid + 512)) : 0u;
+                __syncthreads(); // the byte window is complete (and, first time round, fmax / ptab are set)
+                long long left = 16 + len - sb0;                     // stream bytes that belong to this symbol
+                left = left < 0 ? 0 : (left < sym_bytes ? left : sym_bytes);
+                const int live_bits = (int)(((unsigned)left * 8u + (unsigned)p.bps - 1u) / (unsigned)p.bps) * p.bps;
+                cf v[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = tx_point<true>(sbw, ptab, boff[m], live_bits, fmask);
+                bfly8<true>(v);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+                bfly8<true>(v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + (col ^ (t & 6))] = cmul(v[q], z[q]);
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = T[col * TS + (t ^ (col & 6)) + 8 * m];
+                bfly8<true>(v);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+                bfly8<true>(v);
+                // v[q] = N x[col + 64 (t + 8 q)]
+                if (pass == 0) {
+                    float mine = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) mine = fmaxf(mine, fmaxf(v[q].x, v[q].y) * (1.0f / N));
+#pragma unroll
+                    for (int sh = 32; sh >= 1; sh >>= 1) mine = fmaxf(mine, __shfl_xor(mine, sh, 64));
+                    if (lane == 0) atomicMax(fmax, __float_as_uint(mine));
+                    __syncthreads(); // every wavefront has read its stage-B inputs out of T; the byte window is free
+                    continue;
+                }
+                const float mx = fmaxf(p.header_max, __uint_as_float(*fmax));
+                __syncthreads(); // every wavefront has read its stage-B inputs out of T
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    T[(t + 8 * q) * TS + (col ^ (t & 6))] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
+                __syncthreads();
+                {   // prefix_block: out = [x[N - CP .. N), x[0 .. N)], 16 bytes per lane
+                    float4 *dst4 = reinterpret_cast<float4 *>(row + (long long)(10 + k) * S);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = tid + 512 * j, n = 2 * i;
+                        const float4 y = *reinterpret_cast<const float4 *>(T + (n >> 6) * TS + ((n & 63) ^ ((n >> 6) & 6)));
+                        dst4[(CP >> 1) + i] = y;
+                        if (j == 3) dst4[i - ((N - CP) >> 1)] = y;
+                    }
+                }
+                __syncthreads(); // the byte window / T are reused by the next symbol
+            }
+            if (pass == 0) { // header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
+                __syncthreads();
+                const float mx = fmaxf(p.header_max, __uint_as_float(*fmax));
+                float4 *dst4 = reinterpret_cast<float4 *>(row);
+                const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
+                for (int i = tid; i < 5 * S; i += 512) {
+                    const float4 h = h4[i];
+                    dst4[i] = make_float4(h.x / mx, h.y / mx, h.z / mx, h.w / mx);
+                }
+            }
+        }
+        __syncthreads(); // fmax is reset for the next frame
+    }
+}
+
+// encode for N = 4096 in one pass.  hipErrorNotSupported => caller runs k_sym<4096, M_TX> + k_tx_finish.
+hipError_t run_txframe4096(const SymParams &sp, const float2 *header, float header_max, hipStream_t st, int num_cu) {
+    if (sp.tx_raw_total >= 0 || sp.syms_per_frame <= 0) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(sp.out) & 15) || (sp.out_stride_s & 1)) return hipErrorNotSupported;
+    const int nd = sp.guard ? 48 * 64 : 4096;
+    if ((nd * sp.bps / 8) & 3) return hipErrorNotSupported;
+    if (sp.n_frames <= 0) return hipSuccess;
+    TxFrame4096Params p;
+    p.payload = sp.payload; p.payload_stride = sp.payload_stride; p.payload_len = sp.payload_len; p.payload_bytes = sp.payload_bytes;
+    p.n_frames = sp.n_frames; p.D = sp.syms_per_frame; p.tw = sp.tw; p.header = header; p.header_max = header_max;
+    p.out = sp.out; p.out_stride = sp.out_stride_s; p.bps = sp.bps;
+    const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 16 + 256 * sizeof(float2) + 16;
+    hipError_t e = sp.guard ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_txframe4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                            : hipFuncSetAttribute(reinterpret_cast<const void *>(k_txframe4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    long long grid = (long long)num_cu * 2;
+    if (const char *e = getenv("OFDM_MID_GRID")) { const long long v = atoll(e); if (v > 0 && v < grid) grid = v; } // test hook, as kernels_mid.hip
+    if (grid > p.n_frames) grid = p.n_frames;
+    if (sp.guard) hipLaunchKernelGGL(k_txframe4096<true>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL(k_txframe4096<false>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
 // Persistent grid: resident workgroups per CU from the occupancy API (per instantiation and device, cached), doubled up
 // to the 8 the round-1 launcher used -- measured (OFDM_DEMOD64_WG_PER_CU sweep, 1 M frames): 3 -> 1.77 ms, 4 -> 1.70,
 // 5 -> 1.81, 8 -> 1.68: a second, queued round of workgroups evens out the tail.

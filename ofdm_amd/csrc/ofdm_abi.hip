@@ -739,6 +739,12 @@ int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, 
         if (fe == hipSuccess) return OFDM_OK;
         if (fe != hipErrorNotSupported) { c->last_hip = (int)fe; return OFDM_ERR_HIP; }
     }
+    if (c->prm.n_fft == 4096) { // 64 x 64 two-stage kernel, frames built twice: one pass over HBM (kernels_fast.hip)
+        static const bool off = getenv("OFDM_NO_DEMOD4096") != nullptr;
+        hipError_t fe = off ? hipErrorNotSupported : run_txframe4096(p, c->d_header, c->header_max, c->stream, c->num_cu);
+        if (fe == hipSuccess) return OFDM_OK;
+        if (fe != hipErrorNotSupported) { c->last_hip = (int)fe; return OFDM_ERR_HIP; }
+    }
     void *mx;
     int rc = ws_get(c, 0, sizeof(unsigned) * (size_t)n_frames, &mx);
     if (rc) return rc;

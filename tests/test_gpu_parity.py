@@ -521,10 +521,11 @@ def test_tx_encode_batch(api, orc, n, mod, guard, nbytes, ecc):
 
 
 @pytest.mark.parametrize("n,mod,guard,nbytes", [(64, 6, True, 2300), (64, 1, True, 400), (64, 2, False, 1000), (128, 6, True, 200), (128, 2, False, 3), (256, 4, True, 700), (512, 8, True, 2000),
-                                                 (512, 1, False, 100), (1024, 6, False, 2500), (2048, 4, True, 4000)])
+                                                 (512, 1, False, 100), (1024, 6, False, 2500), (2048, 4, True, 4000), (4096, 8, True, 9000),
+                                                 (4096, 2, False, 2500)])
 def test_tx_encode_mid_frames(api, orc, n, mod, guard, nbytes, monkeypatch):
-    """k_txframe_mid (encode in one HBM pass for N = 128 .. 2048 and for N = 64 frames of more than 56 data symbols: every
-    frame built twice, once for its maximum) against the oracle's encode, 11 frames with ragged payload lengths on a 2-workgroup grid (several rounds per workgroup, a last
+    """k_txframe_mid / k_txframe4096 (encode in one HBM pass for N = 128 .. 4096 and for N = 64 frames of more than 56 data
+    symbols: every frame built twice, once for its maximum) against the oracle's encode, 11 frames with ragged payload lengths on a 2-workgroup grid (several rounds per workgroup, a last
     round that is only partly filled).  src/transmitter.rs:11-58, 184-188."""
     import torch
     monkeypatch.setenv("OFDM_MID_GRID", "2")
