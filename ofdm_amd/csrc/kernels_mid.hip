@@ -121,9 +121,15 @@ struct MidRxParams {
     long long hk_stride;
     unsigned char *out;
     long long out_stride;
+    // FRAME = true (the decode chain after timing, src/receiver.rs:20-83): per-frame start of the trimmed frame, CFO and live
+    // symbol count; samples at or past frame_len read as zero (pad_chunk, receiver.rs:203-210)
+    const int32_t *offset;
+    const double *f_delta;
+    const int32_t *nsym_frame;
+    long long frame_len;
 };
 
-template <int R, int BPS, bool GUARD>
+template <int R, int BPS, bool GUARD, bool FRAME>
 __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p) {
     typedef Mid<R> M;
     constexpr int N = M::N, S = M::S, CP = M::CP, LPS = M::LPS, G = M::G, Q = M::Q, TS = M::TS;
@@ -172,13 +178,22 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
     }
     auto fetch = [&](long long sg, cf *dst) {
         if (sg < p.total) {
-            const cf *src = p.in + fn * p.frame_stride + (long long)(p.first_symbol + kn) * S + CP + colA;
+            const long long off = FRAME && p.offset ? p.offset[fn] : 0;
+            const long long n0 = off + (long long)(p.first_symbol + kn) * S + CP + colA; // first sample of this lane, inside the frame
+            const cf *src = p.in + fn * p.frame_stride + n0;
+            const long long room = FRAME ? p.frame_len - n0 : 0;                          // samples from n0 to the end of the capture
             if (R >= 8) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) dst[m] = src[64 * (u + Q * m)];
+                for (int m = 0; m < 8; ++m) {
+                    const int i = 64 * (u + Q * m);
+                    dst[m] = (!FRAME || i < room) ? src[i] : make_float2(0.f, 0.f);
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dst[e] = src[64 * (e % R) + LPS * (e / R)];
+                for (int e = 0; e < 8; ++e) {
+                    const int i = 64 * (e % R) + LPS * (e / R);
+                    dst[e] = (!FRAME || i < room) ? src[i] : make_float2(0.f, 0.f);
+                }
             }
         } else {
 #pragma unroll
@@ -207,7 +222,32 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
         for (int m = 0; m < 8; ++m) v[m] = pre[m];
         fetch(sg + stride, pre);
         if (pending) flush(pending);
-        pending = sg < p.total ? reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes) : nullptr;
+        bool live = sg < p.total;
+        if (FRAME) {
+            if (live && p.nsym_frame && k >= p.nsym_frame[f]) live = false; // fewer symbols in this frame (short capture / failed sync): nothing is written
+            if (!live) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
+            } else if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50); phase reduced in f64
+                const double turns = p.f_delta[f] * 0.15915494309189533577; // 1 / (2 pi)
+                const long long n0 = (long long)(p.first_symbol + k) * S + CP + colA;
+                if (R >= 8) {
+                    cf ph = cfo_phasor(turns, n0 + 64 * u);
+                    const cf st = cfo_phasor(turns, 64 * Q);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
+                } else {
+                    const cf st = cfo_phasor(turns, 64);
+#pragma unroll
+                    for (int i = 0; i < 8 / R; ++i) {
+                        cf ph = cfo_phasor(turns, n0 + LPS * i);
+#pragma unroll
+                        for (int a = 0; a < R; ++a) { v[i * R + a] = cmul(v[i * R + a], ph); ph = cmul(ph, st); }
+                    }
+                }
+            }
+        }
+        pending = live ? reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes) : nullptr;
         // ---- stage A, twiddle, transpose
         stage_a<R, false>(v, tA, u);
 #pragma unroll
@@ -280,7 +320,7 @@ static long long mid_grid(long long steps, int num_cu, int occ) {
     return grid > steps ? steps : grid;
 }
 
-template <int R, int BPS, bool GUARD> hipError_t launch_demod_mid(const MidRxParams &p0, hipStream_t st, int num_cu) {
+template <int R, int BPS, bool GUARD> hipError_t launch_demod_mid(const MidRxParams &p0, bool frame, hipStream_t st, int num_cu) {
     MidRxParams p = p0;
     constexpr int G = Mid<R>::G;
     const long long steps = (p.total + G - 1) / G;
@@ -288,21 +328,22 @@ template <int R, int BPS, bool GUARD> hipError_t launch_demod_mid(const MidRxPar
     const long long adv = grid * G;
     p.step_f = adv / p.syms_per_frame;
     p.step_k = (int)(adv - p.step_f * p.syms_per_frame);
-    hipLaunchKernelGGL((k_demod_mid<R, BPS, GUARD>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    if (frame) hipLaunchKernelGGL((k_demod_mid<R, BPS, GUARD, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_demod_mid<R, BPS, GUARD, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
-template <int R> hipError_t dispatch_demod_mid(const MidRxParams &p, int bps, bool guard, hipStream_t st, int num_cu) {
+template <int R> hipError_t dispatch_demod_mid(const MidRxParams &p, int bps, bool guard, bool frame, hipStream_t st, int num_cu) {
     switch (bps * 2 + (guard ? 1 : 0)) {
-    case 2: return launch_demod_mid<R, 1, false>(p, st, num_cu);
-    case 3: return launch_demod_mid<R, 1, true>(p, st, num_cu);
-    case 4: return launch_demod_mid<R, 2, false>(p, st, num_cu);
-    case 5: return launch_demod_mid<R, 2, true>(p, st, num_cu);
-    case 8: return launch_demod_mid<R, 4, false>(p, st, num_cu);
-    case 9: return launch_demod_mid<R, 4, true>(p, st, num_cu);
-    case 12: return launch_demod_mid<R, 6, false>(p, st, num_cu);
-    case 13: return launch_demod_mid<R, 6, true>(p, st, num_cu);
-    case 16: return launch_demod_mid<R, 8, false>(p, st, num_cu);
-    case 17: return launch_demod_mid<R, 8, true>(p, st, num_cu);
+    case 2: return launch_demod_mid<R, 1, false>(p, frame, st, num_cu);
+    case 3: return launch_demod_mid<R, 1, true>(p, frame, st, num_cu);
+    case 4: return launch_demod_mid<R, 2, false>(p, frame, st, num_cu);
+    case 5: return launch_demod_mid<R, 2, true>(p, frame, st, num_cu);
+    case 8: return launch_demod_mid<R, 4, false>(p, frame, st, num_cu);
+    case 9: return launch_demod_mid<R, 4, true>(p, frame, st, num_cu);
+    case 12: return launch_demod_mid<R, 6, false>(p, frame, st, num_cu);
+    case 13: return launch_demod_mid<R, 6, true>(p, frame, st, num_cu);
+    case 16: return launch_demod_mid<R, 8, false>(p, frame, st, num_cu);
+    case 17: return launch_demod_mid<R, 8, true>(p, frame, st, num_cu);
     }
     return hipErrorNotSupported;
 }
@@ -649,26 +690,29 @@ template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, h
 
 } // namespace
 
-// RX demod of regular symbol streams for N in {128 .. 2048}.  hipErrorNotSupported => caller uses k_sym<N, M_DEMOD>.
+// RX demod for N in {128 .. 2048}: regular symbol streams, and the data symbols of frames after timing (per-frame offset, CFO,
+// live-symbol count, zero-fill past the capture).  hipErrorNotSupported => caller uses k_sym<N, M_DEMOD>.
 hipError_t run_demod_mid(int n_fft, const SymParams &sp, hipStream_t st, int num_cu) {
     if (n_fft < 128 || n_fft > 2048) return hipErrorNotSupported;
-    if (sp.offset || sp.f_delta || sp.nsym_frame || sp.soft) return hipErrorNotSupported;
-    if (sp.syms_per_frame <= 0) return hipErrorNotSupported;
+    if (sp.soft || sp.syms_per_frame <= 0) return hipErrorNotSupported;
     const int S = n_fft + n_fft / 4, R = n_fft / 64;
-    if ((long long)(sp.first_symbol + sp.syms_per_frame) * S > sp.frame_len) return hipErrorNotSupported; // no tail padding
+    const bool frame = sp.offset || sp.f_delta || sp.nsym_frame ||
+                       (long long)(sp.first_symbol + sp.syms_per_frame) * S > sp.frame_len; // tail padding needs the bounds checks
+    if (sp.in_sym_stride != S || sp.in_skip != n_fft / 4) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
     if (sp.hk && sp.hk_stride != 0 && sp.hk_stride != n_fft) return hipErrorNotSupported;
     MidRxParams p;
     p.in = sp.in; p.frame_stride = sp.frame_stride; p.total = sp.n_frames * (long long)sp.syms_per_frame;
     p.syms_per_frame = sp.syms_per_frame; p.first_symbol = sp.first_symbol; p.step_f = 0; p.step_k = 0;
     p.tw = sp.tw; p.hk = sp.hk; p.hk_stride = sp.hk_stride; p.out = sp.out_bytes; p.out_stride = sp.out_stride;
+    p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym_frame = sp.nsym_frame; p.frame_len = sp.frame_len;
     if (p.total <= 0) return hipSuccess;
     switch (R) {
-    case 2: return dispatch_demod_mid<2>(p, sp.bps, sp.guard != 0, st, num_cu);
-    case 4: return dispatch_demod_mid<4>(p, sp.bps, sp.guard != 0, st, num_cu);
-    case 8: return dispatch_demod_mid<8>(p, sp.bps, sp.guard != 0, st, num_cu);
-    case 16: return dispatch_demod_mid<16>(p, sp.bps, sp.guard != 0, st, num_cu);
-    case 32: return dispatch_demod_mid<32>(p, sp.bps, sp.guard != 0, st, num_cu);
+    case 2: return dispatch_demod_mid<2>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
+    case 4: return dispatch_demod_mid<4>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
+    case 8: return dispatch_demod_mid<8>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
+    case 16: return dispatch_demod_mid<16>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
+    case 32: return dispatch_demod_mid<32>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
     }
     return hipErrorNotSupported;
 }

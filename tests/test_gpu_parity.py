@@ -274,6 +274,37 @@ def test_tx_symbols_mid_every_instantiation(api, orc, n, guard, monkeypatch):
             assert rel_err(fused[i], want[i]) < 4 * TOL, (n, mod, guard, i)
 
 
+@pytest.mark.parametrize("n,mod,guard", [(128, 6, True), (256, 2, False), (512, 8, True), (1024, 4, True), (2048, 6, False)])
+def test_rx_demod_mid_frame_mode(api, orc, n, mod, guard, monkeypatch):
+    """k_demod_mid<..., FRAME = true>: what the decode chain asks of the demodulator after timing (src/receiver.rs:20-83) --
+    a per-frame start offset, CFO derotation with sample ids counted from that start, a per-frame channel, and zero-fill past
+    the end of the capture (pad_chunk, receiver.rs:203-210) -- against the oracle, frame by frame, on a 3-workgroup grid."""
+    import torch
+    monkeypatch.setenv("OFDM_MID_GRID", "3")
+    rng = np.random.default_rng(n + mod)
+    S, k, nf = n + n // 4, 7, 6
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    x, _ = make_symbols_np(orc, rng, k * nf, n, guard, mod, snr_db=38.0)
+    x = wide(x).reshape(nf, k * S)
+    offs = rng.integers(0, 97, nf).astype(np.int32)
+    fds = (rng.random(nf) * 1.8 - 0.9) * np.pi / S
+    span = k * S + 96
+    frames = np.zeros((nf, span), np.complex128)
+    for f in range(nf):
+        # the transmitter's samples, shifted by the frame's offset and rotated by +f_delta (src/channel.rs:58-62: exp(+j f (i + 1)))
+        frames[f, offs[f]:offs[f] + k * S] = x[f] * np.exp(1j * fds[f] * (np.arange(k * S) + 1))
+    hks = fc32(1.0 + 0.2 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n))))
+    cut = span - (S // 2 + 13)   # the capture ends inside the last symbol of the frames with the largest offsets
+    out = host(ctx.rx_demod(dev(ctx, fc32(frames)), k, offset=torch.from_numpy(offs).to(ctx.device),
+                            f_delta=torch.from_numpy(fds).to(ctx.device), hk=dev(ctx, hks), frame_len=cut))
+    for f in range(nf):
+        seg = wide(fc32(frames[f]))[: cut][offs[f]:]
+        seg = np.concatenate([seg, np.zeros(max(0, k * S - seg.size), np.complex128)])[: k * S]
+        seg = orc.cfo_rotate(seg, fds[f], 0)
+        want, wsoft = orc.rx_demod(seg, n, guard, mod, hk=wide(hks[f]), want_soft=True)
+        assert_bytes_match(bytes(out[f]), want, wsoft, mod, what=f"frame mode n={n} frame {f}")
+
+
 def test_rx_demod_with_channel_and_tail_padding(api, orc):
     rng = np.random.default_rng(77)
     n, mod = 64, 6
