@@ -68,15 +68,30 @@ def launch_ranks(a):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()  # rank 0 prints the one JSON line (after the closing barrier)
-    rc = 0
-    deadline = time.time() + 120
+    import threading
+
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)  # rank 0 prints the one JSON line
+    reader.start()
+    # A rank that dies early (no device, RCCL failure) would leave the others waiting in the rendezvous for minutes: as soon as
+    # one rank has failed, the rest are ended (exactly the PIDs started above) and the launcher reports the failure.
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            time.sleep(2.0)  # let the others notice on their own first
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
     for p in procs:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()  # exactly the PID started above
-            p.wait()
+        p.wait()
+    reader.join(timeout=10.0)
+    out0 = (buf[0] if buf else b"").decode()
+    rc = 0
+    for p in procs:
         rc = rc or p.returncode
     json_lines = [ln for ln in out0.splitlines() if ln.lstrip().startswith("{")]
     for ln in out0.splitlines():  # library chatter on rank 0's stdout (gloo / RCCL banners) goes to stderr: stdout carries ONE JSON line
@@ -158,7 +173,10 @@ def dry_run(a):
     """The N-rank plumbing without the GPU: rendezvous, barrier, max / sum reductions, one JSON line from rank 0."""
     from ofdm_amd.dist import Group
 
-    grp = Group()
+    if os.environ.get("OFDM_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):  # test hook: this rank dies before the rendezvous
+        sys.exit(7)
+    # never RCCL here: the dry run uses no GPU, and N RCCL ranks on a box with fewer than N GPUs would wait for each other
+    grp = Group(backend=os.environ.get("OFDM_DIST_BACKEND") or "gloo")
     if grp.world != a.gpus:
         print(f"bench.py: --gpus {a.gpus} but {grp.world} rank(s) came up", file=sys.stderr)
         sys.exit(3)

@@ -103,6 +103,16 @@ def test_bench_refuses_a_mismatched_world():
     assert rc != 0 and not recs
 
 
+def test_bench_ends_all_ranks_when_one_dies():
+    """A rank that dies before the rendezvous must not leave the launcher waiting for the others' rendezvous timeout: the
+    launcher ends the remaining ranks and exits non-zero within seconds."""
+    import time
+    t0 = time.time()
+    rc, recs, lines, err = _run_bench("--gpus", "2", "--dry-run", env={"OFDM_BENCH_FAIL_RANK": "1"})
+    assert rc != 0 and not recs
+    assert time.time() - t0 < 60.0
+
+
 def test_build_lock_serialises_concurrent_builders():
     """Two processes calling ofdm_amd.build.build() at once must not overlap inside the locked region."""
     import subprocess
