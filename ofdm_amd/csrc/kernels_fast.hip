@@ -657,9 +657,15 @@ struct Big4096Params {
     unsigned char *out;
     long long out_stride;
     int bps, guard;
+    // FRAME = true (the decode chain after timing, src/receiver.rs:20-83): per-frame start of the trimmed frame, CFO and live
+    // symbol count; samples at or past frame_len read as zero (pad_chunk, receiver.rs:203-210)
+    const int32_t *offset;
+    const double *f_delta;
+    const int32_t *nsym_frame;
+    long long frame_len;
 };
 
-template <int BPS, bool GUARD>
+template <int BPS, bool GUARD, bool FRAME>
 __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 waves per SIMD = two workgroups per CU: never more than 128 VGPRs
     constexpr int N = 4096, S = 5120, CP = 1024, TS = 72, SLAB = 8 * 72;
     constexpr int ND = GUARD ? 48 * 64 : N;
@@ -697,9 +703,12 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     int kn = (int)(blockIdx.x - fn * p.syms_per_frame);
     auto fetch = [&](long long sg, cf *dst) {
         if (sg < p.total) {
-            const cf *src = p.in + fn * p.frame_stride + (long long)(p.first_symbol + kn) * S + CP + col;
+            const long long off = FRAME && p.offset ? p.offset[fn] : 0;
+            const long long n0 = off + (long long)(p.first_symbol + kn) * S + CP + col;
+            const cf *src = p.in + fn * p.frame_stride + n0;
+            const long long room = FRAME ? p.frame_len - n0 : 0;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) dst[m] = src[64 * (t + 8 * m)];
+            for (int m = 0; m < 8; ++m) dst[m] = (!FRAME || 64 * (t + 8 * m) < room) ? src[64 * (t + 8 * m)] : make_float2(0.f, 0.f);
         } else {
 #pragma unroll
             for (int m = 0; m < 8; ++m) dst[m] = make_float2(0.f, 0.f);
@@ -726,7 +735,21 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
         for (int m = 0; m < 8; ++m) v[m] = pre[m];
         fetch(sg + gridDim.x, pre);
         if (pending) flush(pending);
-        pending = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes);
+        bool live = true;
+        if (FRAME) {
+            if (p.nsym_frame && k >= p.nsym_frame[f]) live = false; // fewer symbols in this frame: nothing is written (workgroup-uniform)
+            if (!live) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
+            } else if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50); phase reduced in f64
+                const double turns = p.f_delta[f] * 0.15915494309189533577;
+                cf ph = cfo_phasor(turns, (long long)(p.first_symbol + k) * S + CP + col + 64 * t);
+                const cf st = cfo_phasor(turns, 512);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
+            }
+        }
+        pending = live ? reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes) : nullptr;
         // ---- stage A: FFT64 over a (wave-local)
         bfly8<false>(v);
 #pragma unroll
@@ -819,11 +842,13 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     if (pending) flush(pending);
 }
 
-// N = 4096 RX demod fast path.  hipErrorNotSupported => caller uses k_sym<4096, M_DEMOD>.
+// N = 4096 RX demod fast path: regular symbol streams, and the data symbols of frames after timing (per-frame offset, CFO,
+// live-symbol count, zero-fill past the capture).  hipErrorNotSupported => caller uses k_sym<4096, M_DEMOD>.
 hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
-    if (sp.offset || sp.f_delta || sp.nsym_frame || sp.soft) return hipErrorNotSupported;
-    if (sp.syms_per_frame <= 0) return hipErrorNotSupported;
-    if ((long long)(sp.first_symbol + sp.syms_per_frame) * 5120 > sp.frame_len) return hipErrorNotSupported; // no tail padding
+    if (sp.soft || sp.syms_per_frame <= 0) return hipErrorNotSupported;
+    if (sp.in_sym_stride != 5120 || sp.in_skip != 1024) return hipErrorNotSupported;
+    const bool frame = sp.offset || sp.f_delta || sp.nsym_frame ||
+                       (long long)(sp.first_symbol + sp.syms_per_frame) * 5120 > sp.frame_len; // tail padding needs the bounds checks
     const int nd = sp.guard ? 48 * 64 : 4096;
     if ((nd * sp.bps / 8) % 4 != 0 || (reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
     if (sp.hk && sp.hk_stride != 0 && sp.hk_stride != 4096) return hipErrorNotSupported;
@@ -831,20 +856,23 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     p.in = sp.in; p.frame_stride = sp.frame_stride; p.total = sp.n_frames * (long long)sp.syms_per_frame;
     p.syms_per_frame = sp.syms_per_frame; p.first_symbol = sp.first_symbol; p.tw = sp.tw; p.hk = sp.hk; p.hk_stride = sp.hk_stride;
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.bps = sp.bps; p.guard = sp.guard;
+    p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym_frame = sp.nsym_frame; p.frame_len = sp.frame_len;
     if (p.total <= 0) return hipSuccess;
     const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64;
     long long grid = (long long)num_cu * 2;
+    if (const char *e = getenv("OFDM_MID_GRID")) { const long long v = atoll(e); if (v > 0 && v < grid) grid = v; } // test hook, as kernels_mid.hip
     if (grid > p.total) grid = p.total;
     p.step_f = grid / p.syms_per_frame; p.step_k = (int)(grid - p.step_f * p.syms_per_frame);
     // > 64 KB of dynamic LDS: a per-device attribute, so set on every call (one process may drive several GPUs); once per batch
-#define OFDM_LAUNCH_4096(B, G)                                                                                              \
+#define OFDM_LAUNCH_4096_F(B, G, F)                                                                                         \
     {                                                                                                                       \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_demod4096<B, G>),                               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_demod4096<B, G, F>),                            \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         if (e != hipSuccess) return e;                                                                                      \
-        hipLaunchKernelGGL((k_demod4096<B, G>), dim3((unsigned)grid), dim3(512), lds, st, p);                               \
+        hipLaunchKernelGGL((k_demod4096<B, G, F>), dim3((unsigned)grid), dim3(512), lds, st, p);                            \
         return hipGetLastError();                                                                                           \
     }
+#define OFDM_LAUNCH_4096(B, G) { if (frame) OFDM_LAUNCH_4096_F(B, G, true) else OFDM_LAUNCH_4096_F(B, G, false) }
     switch (sp.bps * 2 + (sp.guard ? 1 : 0)) {
     case 2: OFDM_LAUNCH_4096(1, false) case 3: OFDM_LAUNCH_4096(1, true)
     case 4: OFDM_LAUNCH_4096(2, false) case 5: OFDM_LAUNCH_4096(2, true)
@@ -852,6 +880,7 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     case 12: OFDM_LAUNCH_4096(6, false) case 13: OFDM_LAUNCH_4096(6, true)
     case 16: OFDM_LAUNCH_4096(8, false) case 17: OFDM_LAUNCH_4096(8, true)
     }
+#undef OFDM_LAUNCH_4096_F
 #undef OFDM_LAUNCH_4096
     return hipErrorNotSupported;
 }

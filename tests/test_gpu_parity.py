@@ -274,9 +274,10 @@ def test_tx_symbols_mid_every_instantiation(api, orc, n, guard, monkeypatch):
             assert rel_err(fused[i], want[i]) < 4 * TOL, (n, mod, guard, i)
 
 
-@pytest.mark.parametrize("n,mod,guard", [(128, 6, True), (256, 2, False), (512, 8, True), (1024, 4, True), (2048, 6, False)])
+@pytest.mark.parametrize("n,mod,guard", [(128, 6, True), (256, 2, False), (512, 8, True), (1024, 4, True), (2048, 6, False),
+                                         (4096, 8, True), (4096, 6, False)])
 def test_rx_demod_mid_frame_mode(api, orc, n, mod, guard, monkeypatch):
-    """k_demod_mid<..., FRAME = true>: what the decode chain asks of the demodulator after timing (src/receiver.rs:20-83) --
+    """k_demod_mid<..., FRAME = true> / k_demod4096<..., FRAME = true>: what the decode chain asks of the demodulator after timing (src/receiver.rs:20-83) --
     a per-frame start offset, CFO derotation with sample ids counted from that start, a per-frame channel, and zero-fill past
     the end of the capture (pad_chunk, receiver.rs:203-210) -- against the oracle, frame by frame, on a 3-workgroup grid."""
     import torch
