@@ -51,7 +51,7 @@ __device__ __forceinline__ unsigned pinned(unsigned v) { asm volatile("" : "+v"(
 // a multiple of 288 bytes: 2.25 lines, shared with the neighbours).  Needs a contiguous output (rows back to back).
 template <int BPS, bool GUARD, bool HK, int BURST = 1>
 __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
-    constexpr int N = 64, S = 80, CP = 16;
+    constexpr int S = 80, CP = 16;
     constexpr int ND = GUARD ? 48 : 64;          // data carriers per symbol
     constexpr int REGION_DW = ND * BPS / 4;      // packed output of 8 symbols, in dwords
     constexpr int SLAB = 8 * 72;                 // 8 symbols x (64 + 8 pad) points
@@ -606,7 +606,7 @@ template <int BPS> static hipError_t launch_txframe(const TxFrame64Params &p, bo
 // Fused TX for N = 64 frames of up to 56 data symbols.  hipErrorNotSupported => caller uses k_sym<M_TX> + k_tx_finish.
 hipError_t run_txframe64(const SymParams &sp, const float2 *header, float header_max, hipStream_t st, int num_cu) {
     const int n_sym = sp.syms_per_frame;
-    if (n_sym <= 0 || n_sym > 56 || !sp.payload && sp.payload_bytes) return hipErrorNotSupported;
+    if (n_sym <= 0 || n_sym > 56 || (!sp.payload && sp.payload_bytes)) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(sp.out) & 15) || (sp.out_stride_s & 1)) return hipErrorNotSupported; // 16-byte stores
     if (sp.n_frames <= 0) return hipSuccess;
     TxFrame64Params p;

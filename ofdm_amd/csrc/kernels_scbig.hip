@@ -32,7 +32,6 @@ namespace {
 constexpr int B_TILE = 2560;   // samples per chunk-sum tile (256 threads x 10)
 constexpr int F_WG = 64;        // one wavefront per frame; tiles of 5 or 10 lags per thread (run_sc_big): 11 / 21 KB of LDS, 12 / 7 frames
                                 // in flight per CU (128 threads / 1280 lags: 3 per CU, 25 % slower)
-constexpr int F_TILE_MAX = 10 * F_WG; // lags per fine tile (k_scb_fine<10>; <5> halves it: see run_sc_big)
 
 struct BSums { double pr, pi, e, r; };
 __device__ __forceinline__ BSums bs_add(BSums a, BSums b) { return BSums{a.pr + b.pr, a.pi + b.pi, a.e + b.e, a.r + b.r}; }
