@@ -46,7 +46,7 @@ __device__ __forceinline__ unsigned lds_offset(const void *p) {
 // that produced it inside the loop (to stay under 96 VGPRs), once per use and iteration.
 __device__ __forceinline__ unsigned pinned(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
-// BURST: a wavefront takes BURST consecutive 8-symbol groups per step and stores their packed images together -- for the
+// BURST (4, 8 or 16): a wavefront takes BURST consecutive 8-symbol groups per step and stores their packed images together -- for the
 // 288-byte images of 64-QAM with guard bands, 4 groups = 1152 bytes = nine WHOLE 128-byte lines (one group's image starts at
 // a multiple of 288 bytes: 2.25 lines, shared with the neighbours).  Needs a contiguous output (rows back to back).
 template <int BPS, bool GUARD, bool HK, int BURST = 1>
@@ -1432,8 +1432,12 @@ template <int BPS, bool GUARD, bool HK> static hipError_t launch_demod64(Fast64P
     static const bool no_burst = getenv("OFDM_DEMOD64_NO_BURST") != nullptr; // A/B
     const bool burst = BPS == 6 && GUARD && !HK && !no_burst && p.wide_stores && p.n_groups % 4 == 0 &&
                        p.out_stride == (long long)p.groups_per_frame * region_bytes && (reinterpret_cast<uintptr_t>(p.out) & 127) == 0;
-    auto kernel = burst ? k_demod64<6, true, false, 4> : k_demod64<BPS, GUARD, HK, 1>;
-    const long long units = burst ? p.n_groups / 4 : p.n_groups;
+    // 16 groups per burst where the batch divides (4.6 KB of stores per wavefront step; 37 KB of LDS per workgroup still leaves four
+    // resident): 1.784 -> 1.761 ms per 1 M frames against bursts of 4 on a box of the slow population; OFDM_DEMOD64_BURST caps it (A/B)
+    static const int burst_cap = [] { const char *v = getenv("OFDM_DEMOD64_BURST"); const int b = v ? atoi(v) : 16; return (b == 4 || b == 8) ? b : 16; }();
+    const int bl = !burst ? 1 : (burst_cap >= 16 && p.n_groups % 16 == 0) ? 16 : (burst_cap >= 8 && p.n_groups % 8 == 0) ? 8 : 4;
+    auto kernel = !burst ? k_demod64<BPS, GUARD, HK, 1> : bl == 16 ? k_demod64<6, true, false, 16> : bl == 8 ? k_demod64<6, true, false, 8> : k_demod64<6, true, false, 4>;
+    const long long units = burst ? p.n_groups / bl : p.n_groups;
     long long waves = (units + 3) / 4 * 4;
     static const int knob = [] { const char *v = getenv("OFDM_DEMOD64_WG_PER_CU"); return v ? atoi(v) : 0; }(); // tuning knob
     const long long cap = (long long)num_cu * (knob > 0 ? knob : (resident_blocks(kernel, 256) >= 4 ? 8 : 2 * resident_blocks(kernel, 256))) * 4;

@@ -166,7 +166,7 @@ def test_rx_demod_fast64_every_instantiation(api, orc, mod, guard, hk_on):
     and for three of the combinations enough groups (> 8192 = 256 CUs x 8 workgroups x 4 waves) that the persistent grid
     wraps.  src/receiver.rs:99-190."""
     big = (mod, guard, hk_on) in ((6, True, False), (6, True, True), (2, False, False))
-    frames24 = 2760 if big else 1032            # frames of 24 symbols; x3 / x1.5 frames of 8 / 16
+    frames24 = 2752 if big else 1032            # frames of 24 symbols; x3 / x1.5 frames of 8 / 16 (8256 / 3096 groups: store bursts of 16 / 8)
     nsym = frames24 * 24
     rng = np.random.default_rng(4000 + 10 * mod + 2 * guard + hk_on)
     x, data = make_symbols_np(orc, rng, nsym, 64, guard, mod, snr_db=34.0)
@@ -1147,7 +1147,7 @@ def test_large_batch_properties(api, orc):
     import torch
     ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
     g = torch.Generator(device=ctx.device); g.manual_seed(7)
-    F, syms = 65536, 16
+    F, syms = 131072, 16   # 262144 groups = 16384 store bursts of 16: twice the persistent grid of k_demod64 (8192 wavefronts)
     nb = syms * ctx.bytes_per_symbol
     pay = torch.randint(0, 256, (F * nb,), dtype=torch.uint8, device=ctx.device, generator=g)
     x = ctx.prefix_block(ctx.encode_block(ctx.modulate(pay).view(-1, ctx.data_carriers))).view(F, syms * 80)
