@@ -281,7 +281,7 @@ def main():
         traffic = F * (pm["read_bytes_per_frame"] + pm["write_bytes_per_frame"])
     except Exception:
         pass
-    roof = {"bound": "hbm", "kernel": "ofdm::k_demod64<6, true, false>", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "kernel": "ofdm::k_demod64<6, true, false, 16> (BPS, GUARD, HK, groups per store burst)", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes}
 
