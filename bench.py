@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the config 3 / 4 / 5 reports (headline only)")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the per-length shapes block (N = 1 diagnostic)")
     ap.add_argument("--cfg3-frames", type=int, default=1_000_000, help="BASELINE config 3: 1M frames")
     ap.add_argument("--cfg4-ring", type=int, default=65536, help="config 4: frames in the resident ring")
     ap.add_argument("--cfg4-frames", type=int, default=10_000_000, help="config 4: frames counted (BASELINE: 10M-frame stream)")
@@ -189,11 +190,31 @@ def dry_run(a):
     per_rank = grp.gather_floats(dt * 1e3 / a.steps)
     (dt,) = grp.reduce_max(dt)
     (ranks,) = grp.reduce_sum(1.0)
+    res = {"metric": "complex IQ Msamples/s through RX demod", "value": None, "unit": "Msamples/s",
+           "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps,
+           "dry_run": True, "ranks_seen": int(ranks), "world_size_seen": grp.world,
+           "backend": grp.backend, "ms_per_step_per_rank": per_rank}
+    # the config 3 / 4 / 5 blocks run on EVERY rank (each its own frames / ring / symbol stream) through the same barrier +
+    # max-over-ranks reduction; here with sleeps in place of the kernels, so that the N-rank flow of those blocks is rehearsed
+    # without a GPU (tests/test_dist_cpu.py)
+    if not a.no_cfg3:
+        from ofdm_amd.dist import shard_range
+        for name in ("cfg3", "cfg5", "cfg4"):
+            grp.barrier()
+            t0 = time.perf_counter()
+            time.sleep(0.002 * (grp.rank + 1))
+            ms = (time.perf_counter() - t0) * 1e3
+            grp.barrier()
+            pr = grp.gather_floats(ms)
+            blk = {"dry_run": True, "n_gpus": grp.world, "ms": max(pr), "ms_per_rank": pr}
+            if name == "cfg4":
+                lo, hi = shard_range(a.cfg4_frames, grp.rank, grp.world)
+                (tot,) = grp.reduce_sum(float(hi - lo))
+                blk["stream_frames"] = a.cfg4_frames
+                blk["stream_frames_all_ranks"] = int(tot)
+            res[name] = blk
     if grp.rank == 0:
-        print(json.dumps({"metric": "complex IQ Msamples/s through RX demod", "value": None, "unit": "Msamples/s",
-                          "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps,
-                          "dry_run": True, "ranks_seen": int(ranks), "world_size_seen": grp.world,
-                          "backend": grp.backend, "ms_per_step_per_rank": per_rank}))
+        print(json.dumps(res))
     grp.close()
 
 
@@ -236,6 +257,9 @@ def main():
     def step():
         ctx.rx_demod(x, syms_per_frame=syms, out=out)
 
+    step()
+    headline_dispatch = ctx.last_dispatch()  # which kernel serves the headline (ofdm_last_dispatch)
+
     def barrier():
         torch.cuda.synchronize()
         grp.barrier()
@@ -275,15 +299,41 @@ def main():
     value = n_gpus * samples_per_step * a.steps / dt / 1e6
     kern_s = ev_ms / 1e3 / a.steps
     alg_bytes = F * (syms * ctx.S * 8 + syms * ctx.bytes_per_symbol)  # 8 B/sample read + packed bytes written
-    traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/r02_pmc_traffic.json), scaled to F
+    traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_traffic.json, newest round), scaled to F
+    for rnd in ("r03", "r02"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")))["k_demod64"]
+            traffic = F * (pm["read_bytes_per_frame"] + pm["write_bytes_per_frame"])
+            break
+        except Exception:
+            pass
+    # What THIS box can do, measured in the same process on the same buffers (boxes of this pool differ by up to 10 % on the
+    # write side): the read-only probe in k_demod64's own access pattern, a pure fill, and a device copy.
+    box = {}
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["k_demod64"]
-        traffic = F * (pm["read_bytes_per_frame"] + pm["write_bytes_per_frame"])
-    except Exception:
-        pass
-    roof = {"bound": "hbm", "kernel": "ofdm::k_demod64<6, true, false, 16> (BPS, GUARD, HK, groups per store burst)", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS,
+        def _t(fn, n=5):
+            fn(); torch.cuda.synchronize(); ctx.timer_start()
+            for _ in range(n):
+                fn()
+            return ctx.timer_stop_ms() / n
+        rd_ms = _t(lambda: ctx.hbm_read_probe(x, 0))
+        scratch = torch.empty(1 << 28, dtype=torch.float32, device=ctx.device)   # 1 GiB
+        fill_ms = _t(lambda: scratch.fill_(1.0))
+        half = scratch.numel() // 2
+        copy_ms = _t(lambda: scratch[:half].copy_(scratch[half:]))
+        box = {"box_read_ceiling_gbs": x.numel() * 8 / rd_ms / 1e6,         # algorithmic bytes of the capture / read-only probe time
+               "box_read_probe_ms": rd_ms,
+               "box_write_ceiling_gbs": scratch.numel() * 4 / fill_ms / 1e6,
+               "box_copy_gbs": 2 * half * 4 / copy_ms / 1e6}
+        # the kernel's time if it did nothing but its loads at the probe's rate and its stores at the fill's rate, back to back
+        ideal_ms = rd_ms + out.numel() / (box["box_write_ceiling_gbs"] * 1e6)
+        box["frac_of_box_ceiling"] = ideal_ms / (kern_s * 1e3)
+        del scratch
+    except Exception as e:  # the headline must survive a failing probe
+        box = {"box_probe_error": repr(e)}
+    roof = {"bound": "hbm", "kernel": "ofdm::k_demod64<6, true, false, 16> (BPS, GUARD, HK, groups per store burst)" if headline_dispatch == "k_demod64<burst16>" else "ofdm::" + headline_dispatch, "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes}
+            "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes, "dispatch": headline_dispatch, **box}
 
     res = {
         "metric": "complex IQ Msamples/s through RX demod", "value": value, "unit": "Msamples/s", "n_gpus": n_gpus,
@@ -308,19 +358,35 @@ def main():
 
     # BASELINE configs 3, 4, 5 at their stated sizes on this GPU (rank 0 of a single-GPU run): each block carries its own
     # roofline, bounded-sample CPU baseline and GPU-vs-CPU equality.  The headline line above must survive their failure.
-    if rank == 0 and n_gpus == 1 and not a.no_cfg3:
+    # Every rank runs them (its own captures / ring / symbol stream: BASELINE configs[3] and [4] are defined on 8 GPUs), through
+    # the same barrier + max-over-ranks timing as the headline; the CPU baselines run on rank 0 of a single-GPU run only.
+    if not a.no_cfg3:
         del x, payload, out
         torch.cuda.empty_cache()
+        cpu = (not a.no_cpu) and n_gpus == 1
         for name, fn in (("cfg3", lambda: __import__("tools.bench_cfg3", fromlist=["run"]).run(
-                                     api, torch, a.cfg3_frames, max(3, a.steps // 4), local, cpu=not a.no_cpu)),
-                         ("cfg5", lambda: __import__("tools.bench_large_n", fromlist=["cfg5"]).cfg5(a.cfg5_symbols, 5, cpu=not a.no_cpu)),
-                         ("cfg4", lambda: __import__("tools.bench_large_n", fromlist=["cfg4"]).cfg4(a.cfg4_ring, a.cfg4_frames, cpu=not a.no_cpu))):
+                                     api, torch, a.cfg3_frames, max(3, a.steps // 4), local, cpu=cpu, grp=grp)),
+                         ("cfg5", lambda: __import__("tools.bench_large_n", fromlist=["cfg5"]).cfg5(
+                                     a.cfg5_symbols, 5, cpu=cpu, grp=grp, device=local)),
+                         ("cfg4", lambda: __import__("tools.bench_large_n", fromlist=["cfg4"]).cfg4(
+                                     a.cfg4_ring, a.cfg4_frames, cpu=cpu, grp=grp, device=local))):
+            # A rank that fails inside a block would leave the others waiting at that block's barrier: every rank reports
+            # whether it got through, and a failure anywhere skips the remaining blocks on all ranks.
             try:
-                res[name] = fn()
+                blk = fn()
+                ok = 1.0
             except Exception as e:
                 import traceback
-                res[name] = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
+                blk = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
+                ok = 0.0
+            res[name] = blk
             torch.cuda.empty_cache()
+            if n_gpus > 1:
+                (oks,) = grp.reduce_sum(ok)
+                if oks < n_gpus:
+                    res[name].setdefault("error", "another rank failed in this block")
+                    break
+    if rank == 0 and n_gpus == 1 and not a.no_cfg3 and not a.no_shapes:
         # every transform length the library accepts: symbol-stream TX / RX and frame-level encode against their one-pass
         # rooflines (which lengths run shape-specialised kernels)
         try:

@@ -20,14 +20,27 @@ pub struct ofdm_params {
     pub n_fft: i32, pub cp_len: i32, pub modulation: i32, pub guard_bands: i32, pub ecc: i32,
     pub sync_window_reps: i32, pub sync_backoff: i32, pub cfo_mode: i32, pub sync_threshold: f32,
     pub sync_mode: i32,
-    pub reserved: [i32; 6],
+    pub rx_path: i32,
+    pub reserved: [i32; 5],
 }
 
 pub const OFDM_OK: c_int = 0;
 pub const OFDM_FRAME_SHORT: i32 = -1; // "Input not long enough, bailing early" (src/receiver.rs:27-29)
 pub const OFDM_MOD_BPSK: i32 = 1;
 pub const OFDM_MOD_QPSK: i32 = 2;
+pub const OFDM_MOD_QAM16: i32 = 4;
 pub const OFDM_MOD_QAM64: i32 = 6;
+
+/// The crate's own `ModulationScheme` (src/transmitter.rs:98-104) is what `encode` / `decode` keep taking.  Its `Qam` arm is
+/// empty in the reference (transmitter.rs:135-136, receiver.rs:185: "Only 16 qam is implemented"); here it selects 16-QAM.
+use crate::ModulationScheme;
+fn bits_per_point(m: &ModulationScheme) -> i32 {
+    match m {
+        ModulationScheme::Bpsk => OFDM_MOD_BPSK,
+        ModulationScheme::Qpsk => OFDM_MOD_QPSK,
+        ModulationScheme::Qam => OFDM_MOD_QAM16,
+    }
+}
 
 #[link(name = "ofdm_hip")]
 extern "C" {
@@ -49,6 +62,9 @@ extern "C" {
     pub fn ofdm_set_stream(ctx: *mut ofdm_ctx, stream: *mut c_void) -> c_int;
     pub fn ofdm_synchronize(ctx: *mut ofdm_ctx) -> c_int;
     pub fn ofdm_last_hip_error(ctx: *const ofdm_ctx) -> c_int;
+    pub fn ofdm_last_dispatch(ctx: *const ofdm_ctx, buf: *mut c_char, n: usize) -> c_int;
+    pub fn ofdm_set_tuning(ctx: *mut ofdm_ctx, key: *const c_char, value: i64) -> c_int;
+    pub fn ofdm_get_tuning(ctx: *const ofdm_ctx, key: *const c_char, value: *mut i64) -> c_int;
     pub fn ofdm_dev_alloc(ctx: *mut ofdm_ctx, bytes: usize, dev: *mut *mut c_void) -> c_int;
     pub fn ofdm_dev_free(ctx: *mut ofdm_ctx, dev: *mut c_void) -> c_int;
     pub fn ofdm_memcpy_h2d(ctx: *mut ofdm_ctx, dev: *mut c_void, host: *const c_void, bytes: usize) -> c_int;
@@ -123,9 +139,17 @@ impl Ctx {
 }
 impl Drop for Ctx { fn drop(&mut self) { unsafe { ofdm_destroy(self.raw); } } }
 
-/// `ofdm::encode!(data, guard_bands, modulation)` -- src/transmitter.rs:10-58
-pub fn encode(data: &[u8], guard_bands: Option<bool>, modulation: Option<i32>) -> anyhow::Result<Vec<Complex64>> {
-    let ctx = Ctx::new(guard_bands.unwrap_or(false), modulation.unwrap_or(OFDM_MOD_BPSK))?;
+/// `ofdm::encode!(data, guard_bands, modulation)` -- the reference's exact signature (src/transmitter.rs:10-15), so the
+/// `#[optargs::optfn]` attribute and every `encode!` call site stay as they are.  The reference cannot fail here; a GPU can
+/// (no device, out of memory): like the reference's own `unwrap`s this panics rather than change the return type.
+#[optargs::optfn]
+pub fn encode(data: &[u8], guard_bands: Option<bool>, modulation: Option<crate::ModulationScheme>) -> Vec<Complex64> {
+    try_encode(data, guard_bands, modulation).expect("ofdm_hip encode")
+}
+
+/// Fallible form for hosts that prefer a `Result` over the panic.
+pub fn try_encode(data: &[u8], guard_bands: Option<bool>, modulation: Option<crate::ModulationScheme>) -> anyhow::Result<Vec<Complex64>> {
+    let ctx = Ctx::new(guard_bands.unwrap_or(false), bits_per_point(&modulation.unwrap_or(ModulationScheme::Bpsk)))?;
     let n = unsafe { ofdm_frame_samples(ctx.raw, data.len() as i64) } as usize;
     let d_in = ctx.alloc(data.len().max(1))?;
     let d_out = ctx.alloc(n * 8)?;
@@ -141,9 +165,10 @@ pub fn encode(data: &[u8], guard_bands: Option<bool>, modulation: Option<i32>) -
     }
 }
 
-/// `ofdm::decode!(samples, guard_bands, modulation)` -- src/receiver.rs:8-96
-pub fn decode(samples: Vec<Complex64>, guard_bands: Option<bool>, modulation: Option<i32>) -> anyhow::Result<Vec<u8>> {
-    let ctx = Ctx::new(guard_bands.unwrap_or(false), modulation.unwrap_or(OFDM_MOD_BPSK))?;
+/// `ofdm::decode!(samples, guard_bands, modulation)` -- the reference's exact signature (src/receiver.rs:8-13)
+#[optargs::optfn]
+pub fn decode(samples: Vec<Complex64>, guard_bands: Option<bool>, modulation: Option<crate::ModulationScheme>) -> anyhow::Result<Vec<u8>> {
+    let ctx = Ctx::new(guard_bands.unwrap_or(false), bits_per_point(&modulation.unwrap_or(ModulationScheme::Bpsk)))?;
     let n = samples.len();
     let fc32: Vec<ofdm_fc32> = samples.iter().map(|c| ofdm_fc32 { re: c.re as f32, im: c.im as f32 }).collect(); // sig_to_bytes
     let max_sym = (((n + ctx.s - 1) / ctx.s).saturating_sub(10)).max(1);

@@ -68,6 +68,11 @@ enum { OFDM_CFO_OFF = 0, OFDM_CFO_SIGNED = 1, OFDM_CFO_ABS = 2 }; /* ABS = refer
  * with the locking signal (xcorr_fft, src/signals/mod.rs:186-217; offset = idx_max - N = lag - 1, src/receiver.rs:20-25) and
  * frequency_correction on preamble repetitions 3 and 4 (src/receiver.rs:39, 231-240; always |.|) */
 enum { OFDM_SYNC_SCHMIDL_COX = 0, OFDM_SYNC_REFERENCE = 1 };
+/* how ofdm_rx_decode_batch runs the N = 64 chain (src/receiver.rs:9-96) when Schmidl-Cox timing is on: STAGED = timing kernel,
+ * then one receive kernel per frame (two passes over the capture); ONE_PASS = timing, CFO, channel estimate, demod and the
+ * length-header finish in ONE kernel from one LDS image of the frame (one pass over HBM; frames that do not fit its envelope,
+ * see DESIGN.md 5.2, take the staged chain).  AUTO = the faster of the two as measured on MI355X.  Results are identical. */
+enum { OFDM_RX_AUTO = 0, OFDM_RX_STAGED = 1, OFDM_RX_ONE_PASS = 2 };
 
 typedef struct {
     int32_t n_fft;            /* sub-carriers: 64 (reference) .. 4096, power of two */
@@ -80,7 +85,8 @@ typedef struct {
     int32_t cfo_mode;         /* OFDM_CFO_* , default SIGNED */
     float sync_threshold;     /* packet-detect threshold on M(d), default 0.5 */
     int32_t sync_mode;        /* OFDM_SYNC_*, default SCHMIDL_COX (this slot was reserved[0] == 0: same layout, same default) */
-    int32_t reserved[6];      /* must be zero */
+    int32_t rx_path;          /* OFDM_RX_*, default AUTO (this slot was reserved[0] == 0: same layout, same default) */
+    int32_t reserved[5];      /* must be zero */
 } ofdm_params;
 
 /* ------------------------------------------------------------------ library / context */
@@ -109,6 +115,22 @@ int ofdm_destroy(ofdm_ctx *ctx);
 int ofdm_set_stream(ofdm_ctx *ctx, void *stream);
 int ofdm_synchronize(ofdm_ctx *ctx);
 int ofdm_last_hip_error(const ofdm_ctx *ctx); /* raw hipError_t of the last failing HIP call */
+/* Which kernels served the LAST stage-level / pipeline entry point on this context: the names of the kernels its launchers
+ * really enqueued, in order, joined by '+' (e.g. "k_scb_chunks<contig>+k_scb_fine<5>+k_rx_prepare+k_rxframe1024+k_rx_finish").
+ * Every shape-specialised launcher has a generic fallback (k_sym<...>) for requests outside its envelope -- unaligned or
+ * oddly strided buffers, soft outputs -- with the same results; this call is how a caller (and the parity tests) tell which
+ * one ran.  Returns the full length of the string (like snprintf), buf receives at most n - 1 characters. Host call. */
+int ofdm_last_dispatch(const ofdm_ctx *ctx, char *buf, size_t n);
+/* Per-context tuning: A/B switches between kernel families and grid shapes.  The library reads NO environment variable.
+ * Keys (value >= 0): "one_pass_rx" 0/1 (overrides ofdm_params.rx_path), "no_sc_big", "no_fast64", "no_demod4096",
+ * "no_mid_kernels", "no_rxframe1024", "no_txframe64" (1 = take the generic kernel instead of that family), "grid_cap"
+ * (> 0: caps every persistent grid -- the tests use it to run many pipeline steps per workgroup on small batches),
+ * "tx_waves", "sc_wg_per_cu", "demod64_wg_per_cu", "demod64_burst" (16 / 8 / 4 / 1), "demod64_narrow_stores",
+ * "scb_two_segments", "scb_big_tiles"; "debug_demod64", "debug_sc", "debug_tx" select ablation exits / section timers
+ * that exist only in the profile build of the library (libofdm_hip_profile.so, -DOFDM_PROFILE_BUILD=1): the product build
+ * answers OFDM_ERR_UNSUPPORTED.  Unknown key: OFDM_ERR_INVALID.  ofdm_get_tuning also answers "profile_build". Host calls. */
+int ofdm_set_tuning(ofdm_ctx *ctx, const char *key, int64_t value);
+int ofdm_get_tuning(const ofdm_ctx *ctx, const char *key, int64_t *value);
 
 /* device-memory helpers so a host without its own HIP binding (the Rust crate) can stage buffers */
 int ofdm_dev_alloc(ofdm_ctx *ctx, size_t bytes, void **dev);

@@ -7,6 +7,16 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libofdm_hip.so")
 _lib = None
+_profile = False
+
+
+def use_profile_build():
+    """tools/ only: load libofdm_hip_profile.so (the build with the kernels' ablation exits and section timers, reachable
+    through ofdm_set_tuning "debug_*") instead of the product library.  Must be called before the first load()."""
+    global _profile
+    if _lib is not None and not _profile:
+        raise RuntimeError("use_profile_build() must precede the first load()")
+    _profile = True
 
 i32, i64, u8p, vp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p
 
@@ -17,7 +27,7 @@ class Params(C.Structure):
     _fields_ = [
         ("n_fft", C.c_int32), ("cp_len", C.c_int32), ("modulation", C.c_int32), ("guard_bands", C.c_int32),
         ("ecc", C.c_int32), ("sync_window_reps", C.c_int32), ("sync_backoff", C.c_int32), ("cfo_mode", C.c_int32),
-        ("sync_threshold", C.c_float), ("sync_mode", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("sync_threshold", C.c_float), ("sync_mode", C.c_int32), ("rx_path", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -40,6 +50,9 @@ SIGNATURES = {
     "ofdm_set_stream": (C.c_int, [vp, vp]),
     "ofdm_synchronize": (C.c_int, [vp]),
     "ofdm_last_hip_error": (C.c_int, [vp]),
+    "ofdm_last_dispatch": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "ofdm_set_tuning": (C.c_int, [vp, C.c_char_p, i64]),
+    "ofdm_get_tuning": (C.c_int, [vp, C.c_char_p, C.POINTER(i64)]),
     "ofdm_dev_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "ofdm_dev_free": (C.c_int, [vp, vp]),
     "ofdm_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
@@ -81,7 +94,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    if _profile:
+        from . import build as _build
+
+        path = _build.build(profile=True)
+    elif not os.path.exists(LIB_PATH):
         from . import build as _build
 
         _build.build()
@@ -90,9 +108,9 @@ def load() -> C.CDLL:
     import torch  # noqa: F401
 
     try:
-        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     except OSError as e:  # no silent fallback
-        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+        raise RuntimeError(f"cannot load {path}: {e}") from e
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res

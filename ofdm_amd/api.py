@@ -22,6 +22,8 @@ ECC_NONE, ECC_HAMMING74 = 0, 1
 CFO_OFF, CFO_SIGNED, CFO_ABS = 0, 1, 2
 FRAME_OK, FRAME_SHORT, FRAME_NOSYNC, FRAME_BADTIMING, FRAME_HEADER = 0, -1, -2, -3, -4
 SYNC_SCHMIDL_COX, SYNC_REFERENCE = 0, 1
+RX_AUTO, RX_STAGED, RX_ONE_PASS = 0, 1, 2
+DEFAULT_TUNING: dict = {}  # merged under every Context's `tuning=` (tools/tune_env.py fills it; empty in tests, bench and smoke)
 
 
 class OfdmError(RuntimeError):
@@ -107,7 +109,7 @@ class Context:
                  device: int = 0, preamble: Optional[np.ndarray] = None, training: Optional[np.ndarray] = None,
                  sync_window_reps: int = 3, sync_backoff: int = 4, cfo_mode: int = CFO_SIGNED,
                  sync_threshold: float = 0.5, use_torch_stream: bool = True, pilots: str = "default",
-                 sync_mode: int = SYNC_SCHMIDL_COX):
+                 sync_mode: int = SYNC_SCHMIDL_COX, rx_path: int = RX_AUTO, tuning: Optional[dict] = None):
         self.lib = _lib.load()
         if pilots == "stdrng":  # the reference's own tables (restated, unverified) unless explicit tables are given
             sp, st = stdrng_pilots(n_fft)
@@ -124,6 +126,7 @@ class Context:
         p.sync_window_reps, p.sync_backoff, p.cfo_mode, p.sync_threshold = (sync_window_reps, sync_backoff, cfo_mode,
                                                                             sync_threshold)
         p.sync_mode = sync_mode
+        p.rx_path = rx_path
         self.params = p
         pre = None if preamble is None else np.ascontiguousarray(preamble, dtype=np.complex128)
         trn = None if training is None else np.ascontiguousarray(training, dtype=np.complex128)
@@ -142,6 +145,8 @@ class Context:
         self.modulation, self.guard_bands, self.ecc = modulation, bool(guard_bands), ecc
         self.data_carriers = self.lib.ofdm_data_carriers(h)
         self.bytes_per_symbol = self.lib.ofdm_bytes_per_symbol(h)
+        for k, v in {**DEFAULT_TUNING, **(tuning or {})}.items():
+            self.set_tuning(k, v)
 
     def close(self):
         if getattr(self, "h", None):
@@ -160,6 +165,23 @@ class Context:
 
     def synchronize(self):
         self._ck(self.lib.ofdm_synchronize(self.h), "ofdm_synchronize")
+
+    def set_tuning(self, key: str, value: int):
+        """ofdm_set_tuning: per-context A/B switches and grid shapes (keys in include/ofdm_hip.h)."""
+        self._ck(self.lib.ofdm_set_tuning(self.h, key.encode(), int(value)), f"ofdm_set_tuning({key})")
+
+    def get_tuning(self, key: str) -> int:
+        v = C.c_int64()
+        self._ck(self.lib.ofdm_get_tuning(self.h, key.encode(), C.byref(v)), f"ofdm_get_tuning({key})")
+        return int(v.value)
+
+    def last_dispatch(self) -> str:
+        """The kernels the last entry point launched, e.g. 'k_rx_prepare+k_rxframe64<finish>' (ofdm_last_dispatch)."""
+        buf = C.create_string_buffer(512)
+        n = self.lib.ofdm_last_dispatch(self.h, buf, len(buf))
+        if n < 0:
+            self._ck(n, "ofdm_last_dispatch")
+        return buf.value.decode()
 
     def coded_len(self, payload_bytes: int) -> int:
         return int(self.lib.ofdm_coded_len(self.h, payload_bytes))

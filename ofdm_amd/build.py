@@ -15,6 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libofdm_hip.so")
+# the profile build (-DOFDM_PROFILE_BUILD=1): same sources with the kernels' ablation exits and s_memtime section timers compiled
+# in; used by tools/ only (ofdm_amd._lib.use_profile_build()), never by the tests, the bench line or smoke()
+LIB_PROFILE = os.path.join(HERE, "libofdm_hip_profile.so")
+OBJ_PROFILE = os.path.join(CSRC, "_obj_profile")
 SOURCES = ["kernels_sym.hip", "kernels_fast.hip", "kernels_mid.hip", "kernels_sync.hip", "kernels_scbig.hip", "kernels_bytes.hip", "ofdm_abi.hip", "outer_code.hip"]
 HEADERS = ["device_common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "ofdm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -58,22 +62,24 @@ class _BuildLock:
         return False
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, profile: bool = False) -> str:
     with _BuildLock():
-        return _build_locked(force, verbose)
+        return _build_locked(force, verbose, profile)
 
 
-def _build_locked(force: bool, verbose: bool) -> str:
+def _build_locked(force: bool, verbose: bool, profile: bool = False) -> str:
     hipcc = _hipcc()
-    os.makedirs(OBJ, exist_ok=True)
+    obj_dir, lib = (OBJ_PROFILE, LIB_PROFILE) if profile else (OBJ, LIB)
+    flags = FLAGS + (["-DOFDM_PROFILE_BUILD=1"] if profile else [])
+    os.makedirs(obj_dir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
+            jobs.append([hipcc, *flags, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -85,13 +91,13 @@ def _build_locked(force: bool, verbose: bool) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
-    if force or jobs or _stale(LIB, objs):
-        tmp = LIB + f".tmp{os.getpid()}"  # link beside the target, then rename: a reader never sees a half-written .so
+    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in srcs]
+    if force or jobs or _stale(lib, objs):
+        tmp = lib + f".tmp{os.getpid()}"  # link beside the target, then rename: a reader never sees a half-written .so
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs])
-        os.replace(tmp, LIB)
-    return LIB
+        os.replace(tmp, lib)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv))

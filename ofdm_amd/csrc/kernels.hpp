@@ -3,9 +3,49 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef OFDM_PROFILE_BUILD
+#define OFDM_PROFILE_BUILD 0 // 1 (ofdm_amd/build.py, profile=True): libofdm_hip_profile.so with the ablation / section-timing branches
+#endif
+
 namespace ofdm {
 
+// The `debug` branches of the kernels (early exits, s_memtime section ticks) are compiled only into the profile build.
+constexpr bool kProfile = OFDM_PROFILE_BUILD != 0;
+
+// Per-context tuning (ofdm_set_tuning): A/B switches between kernel families, grid shapes and the tests' grid cap.  The
+// library reads no environment variable; a host that wants one maps it onto these keys itself (tools/tune_env.py).
+struct Tuning {
+    int one_pass_rx = 0;           // N = 64 decode: timing + receive body in ONE kernel / HBM pass (k_sc_cf<..., BPS>) where it fits
+    int no_sc_big = 0;             // long-period Schmidl-Cox through k_sc_tile instead of k_scb_chunks + k_scb_fine
+    int no_fast64 = 0, no_demod4096 = 0, no_mid_kernels = 0, no_rxframe1024 = 0, no_txframe64 = 0; // take the generic k_sym
+    long long grid_cap = 0;        // > 0: caps every persistent grid (test hook: many steps per workgroup on a small batch)
+    int tx_waves = 16;             // k_txframe64: wavefronts per CU
+    int sc_wg_per_cu = 7;          // k_sc_cf: persistent workgroups per CU
+    int demod64_wg_per_cu = 0;     // k_demod64: persistent workgroups per CU (0 = from the occupancy API)
+    int demod64_burst = 16;        // k_demod64: groups per store burst (16 / 8 / 4; 1 = no bursts)
+    int demod64_narrow_stores = 0; // k_demod64: 4-byte instead of 16-byte image stores
+    int scb_two_segments = 0;      // k_scb_chunks: two-segment staging also for L <= 1280
+    int scb_big_tiles = 0;         // k_scb_fine: 1280-lag tiles / 128 threads
+    int debug_demod64 = 0, debug_sc = 0, debug_tx = 0; // profile build only (kProfile)
+};
+inline const Tuning &tuning_or_default(const Tuning *t) { static const Tuning d; return t ? *t : d; }
+
+// Which kernels served the last entry point (ofdm_last_dispatch): every launcher appends the kernel it really launched.
+struct Trace {
+    char buf[256];
+    int len = 0;
+    void reset() { len = 0; buf[0] = 0; }
+    void add(const char *name) {
+        if (len && len < (int)sizeof(buf) - 1) buf[len++] = '+';
+        while (*name && len < (int)sizeof(buf) - 1) buf[len++] = *name++;
+        buf[len] = 0;
+    }
+};
+inline void trace_add(Trace *t, const char *name) { if (t) t->add(name); }
+
 struct SymParams {
+    const Tuning *tune = nullptr; // nullptr = defaults
+    Trace *trace = nullptr;
     // input samples / bins
     const float2 *in = nullptr;
     long long n_frames = 0;
@@ -89,6 +129,8 @@ hipError_t run_tx_symbols(int n, const SymParams &p, hipStream_t st, int num_cu)
 
 // ---- Schmidl-Cox (kernels_sync.hip)
 struct ScParams {
+    const Tuning *tune = nullptr;
+    Trace *trace = nullptr;
     const float2 *in = nullptr;
     long long n_frames = 0, frame_stride = 0, frame_len = 0;
     long long n_lags = 0;        // lags searched per frame (already clipped to the valid range)
@@ -149,9 +191,11 @@ hipError_t run_freq_correction(const float2 *in, long long n_pairs, long long st
 size_t xcorr_workspace_bytes(long long n_frames, long long N, int nb);
 hipError_t run_xcorr(const float2 *a, long long n_frames, long long stride, long long N, const float2 *b, int nb, void *workspace,
                      int32_t *idx_max, float *peak, float2 *out, long long out_stride, int num_cu, hipStream_t st);
-// reference timing -> trimmed offset (src/receiver.rs:21-36): offset = idx_max - N
+// reference timing -> trimmed offset (src/receiver.rs:21-36): offset = idx_max - N.  offset_report (optional) receives that
+// value as it is (negative for quirk Q1), offset_kernels the copy the receive kernels index with (0 unless status == 0)
 hipError_t run_rx_prepare_ref(long long n_frames, const int32_t *idx_max, long long frame_len, int L, int max_symbols,
-                              int bytes_per_symbol, int32_t *status, int32_t *offset, int32_t *nsym, hipStream_t st);
+                              int bytes_per_symbol, int32_t *status, int32_t *offset_report, int32_t *offset_kernels, int32_t *nsym,
+                              hipStream_t st);
 hipError_t run_cfo_rotate(float2 *x, long long n_frames, long long frame_stride, long long frame_len,
                           const double *f_delta, const int32_t *first_index, hipStream_t st);
 

@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void k_rx_prepare(long long n_frames, const in
 // reference timing (src/receiver.rs:21-36): offset = idx_max - ((2N - 1 - 1) / 2 + 1) = idx_max - N = lag - 1 (quirk Q1: a
 // zero-delay capture gives -1, where the reference panics in split_off -> OFDM_FRAME_BADTIMING)
 __global__ __launch_bounds__(256) void k_rx_prepare_ref(long long n_frames, const int32_t *idx_max, long long frame_len, int L,
-                                                        int max_symbols, int bytes_per_symbol, int32_t *status, int32_t *offset,
-                                                        int32_t *nsym) {
+                                                        int max_symbols, int bytes_per_symbol, int32_t *status, int32_t *offset_report,
+                                                        int32_t *offset_kernels, int32_t *nsym) {
     const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
     if (f >= n_frames) return;
     const long long off = (long long)idx_max[f] - frame_len;
@@ -243,14 +243,16 @@ __global__ __launch_bounds__(256) void k_rx_prepare_ref(long long n_frames, cons
         }
     }
     status[f] = st;
-    offset[f] = (int32_t)off;
+    if (offset_report) offset_report[f] = (int32_t)off;  // what the reference would have passed to split_off, negative included
+    offset_kernels[f] = st == 0 ? (int32_t)off : 0;       // what the receive kernels index with: never outside the capture
     nsym[f] = st == 0 ? ns : 0;
 }
 hipError_t run_rx_prepare_ref(long long n_frames, const int32_t *idx_max, long long frame_len, int L, int max_symbols,
-                              int bytes_per_symbol, int32_t *status, int32_t *offset, int32_t *nsym, hipStream_t st) {
+                              int bytes_per_symbol, int32_t *status, int32_t *offset_report, int32_t *offset_kernels, int32_t *nsym,
+                              hipStream_t st) {
     if (n_frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_rx_prepare_ref, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, n_frames, idx_max, frame_len, L,
-                       max_symbols, bytes_per_symbol, status, offset, nsym);
+                       max_symbols, bytes_per_symbol, status, offset_report, offset_kernels, nsym);
     return hipGetLastError();
 }
 

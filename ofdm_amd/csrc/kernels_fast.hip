@@ -19,6 +19,7 @@
 // Roofline: HBM -- 640 algorithmic bytes read per symbol (512 actually fetched) + packed bytes written.
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include <mutex>
 #include <stdlib.h>
 
 extern "C" __device__ float __ocml_atan2pi_f32(float, float); // atan2(y, x) / pi (ROCm device library)
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = src[8 * m];
         bfly8<false>(v);
-        if (p.debug == 3) { // profiling aid: loads + one butterfly
+        if (kProfile && p.debug == 3) { // profiling aid: loads + one butterfly
             float acc = 0.f;
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc += v[m].x + v[m].y;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
         }
-        if (p.debug == 2) { // profiling aid: everything but the packing and the stores
+        if (kProfile && p.debug == 2) { // profiling aid: everything but the packing and the stores
             float acc = 0.f;
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc += v[m].x + v[m].y;
@@ -163,9 +164,9 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
         }
     };
     auto store_image = [&](unsigned *dst, int ndw) { // ndw dwords of this wave's LDS image -> global
-        if (p.debug == 1 || p.debug == 2 || p.debug == 3) { if (img0[lane] == 0x12345678u) dst[0] = 1u; return; } // profiling aid: no stores
-        if (p.debug == 4) dst = reinterpret_cast<unsigned *>(p.out) + (blockIdx.x & 255) * 4 * BURST * REGION_DW + wave * BURST * REGION_DW; // L2-resident window
-        if (p.debug == 5) { for (int i = lane; i < ndw; i += 64) __builtin_nontemporal_store(img0[i], dst + i); return; }
+        if (kProfile && (p.debug == 1 || p.debug == 2 || p.debug == 3)) { if (img0[lane] == 0x12345678u) dst[0] = 1u; return; } // profiling aid: no stores
+        if (kProfile && p.debug == 4) dst = reinterpret_cast<unsigned *>(p.out) + (blockIdx.x & 255) * 4 * BURST * REGION_DW + wave * BURST * REGION_DW; // L2-resident window
+        if (kProfile && p.debug == 5) { for (int i = lane; i < ndw; i += 64) __builtin_nontemporal_store(img0[i], dst + i); return; }
         if ((REGION_DW % 4) == 0 && p.wide_stores) { // 16 bytes per lane
             for (int i = lane; i < ndw / 4; i += 64) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(img0)[i];
         } else for (int i = lane; i < ndw; i += 64) dst[i] = img0[i];
@@ -418,7 +419,9 @@ hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, in
     } else if (final_out) return hipErrorNotSupported;
     p.frame_list = frame_list; p.frame_count = frame_count;
     long long blocks = (sp.n_frames + 3) / 4, cap = frame_list ? 64 : (long long)num_cu * 8;
+    { const long long gc = tuning_or_default(sp.tune).grid_cap; if (gc > 0 && gc < cap) cap = gc; }
     const dim3 grid((unsigned)(blocks < cap ? blocks : cap));
+    trace_add(sp.trace, frame_list ? "k_rxframe64<list>" : (p.final_out ? "k_rxframe64<finish>" : "k_rxframe64"));
     switch (sp.bps) {
     case 2: return launch_rxframe<2>(p, sp.guard != 0, grid, st);
     case 4: return launch_rxframe<4>(p, sp.guard != 0, grid, st);
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
     }
     for (; f < p.n_frames; f += gridDim.x) {
         lds_only_barrier(); // the previous frame has left LDS (and the header is staged)
-        const long long t0 = p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long t0 = kProfile && p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
         const uint8_t *pay = p.payload + f * p.payload_stride;
         if (tid < 4) sbw[tid] = tid < 2 ? (unsigned)((unsigned long long)len >> (32 * tid)) : 0u;
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
             }
         }
         lds_only_barrier();
-        const long long t1 = p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long t1 = kProfile && p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const int npoints = (int)(((16 + len) * 8 + BPS - 1) / BPS); // points that carry stream bits; the rest are 0
         float lmax = 0.f;
         for (int g = wave; g < groups; g += nwaves) {
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
         for (int sh = 32; sh >= 1; sh >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, sh, 64));
         if (lane == 0) atomicMax(mxw, __float_as_uint(lmax)); // non-negative floats order like their bit patterns
         lds_only_barrier();
-        const long long t2 = p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long t2 = kProfile && p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const float inv = 1.0f / fmaxf(p.header_max, __uint_as_float(*mxw)); // one divide per thread, then multiplies (<= 1 ulp)
         // stream [header | data] out: header and data are contiguous in LDS, two samples per 16-byte store
         const int total2 = (HDR + p.n_sym * S) >> 1;
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
             dst[i + 3 * nthr] = make_float4(d.x * inv, d.y * inv, d.z * inv, d.w * inv);
         }
         for (; i < total2; i += nthr) { const float4 a = src4[i]; dst[i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv); }
-        if (p.debug) {
+        if (kProfile && p.debug) {
             __syncthreads();
             if (tid == 0) {
                 const long long t3 = (long long)__builtin_amdgcn_s_memtime();
@@ -613,15 +616,19 @@ hipError_t run_txframe64(const SymParams &sp, const float2 *header, float header
     p.payload = sp.payload; p.payload_stride = sp.payload_stride; p.payload_len = sp.payload_len; p.payload_bytes = sp.payload_bytes;
     p.n_frames = sp.n_frames; p.n_sym = n_sym; p.tw = sp.tw; p.header = header; p.header_max = header_max;
     p.out = sp.out; p.out_stride = sp.out_stride_s;
-    { const char *v = getenv("OFDM_TX_DEBUG"); p.debug = v ? atoi(v) : 0; }
+    const Tuning &tu = tuning_or_default(sp.tune);
+    p.debug = kProfile ? tu.debug_tx : 0;
     const int groups = (n_sym + 7) / 8;
     const size_t lds = (size_t)(800 + groups * 8 * 80) * sizeof(float2) + 16 + (size_t)groups * 8 * 64 + 32; // header + frame + max + byte stream
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
-    static const int waves_per_cu = [] { const char *v = getenv("OFDM_TX_WAVES"); return v ? atoi(v) : 16; }(); // tuning knob (measured best: 16)
-    const long long wave_cap = waves_per_cu / (groups < 4 ? groups : 4); // wavefronts per CU
+    const int waves_per_cu = tu.tx_waves > 0 ? tu.tx_waves : 16; // tuning knob (measured best: 16)
+    long long wave_cap = waves_per_cu / (groups < 4 ? groups : 4); // wavefronts per CU
+    if (wave_cap < 1) wave_cap = 1;
     if (per_cu > wave_cap) per_cu = wave_cap;
     long long grid = (long long)num_cu * per_cu;
+    if (tu.grid_cap > 0 && tu.grid_cap < grid) grid = tu.grid_cap;
     if (grid > sp.n_frames) grid = sp.n_frames;
+    trace_add(sp.trace, "k_txframe64");
     switch (sp.bps) {
     case 1: return launch_txframe<1>(p, sp.guard != 0, dim3((unsigned)grid), lds, st);
     case 2: return launch_txframe<2>(p, sp.guard != 0, dim3((unsigned)grid), lds, st);
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
                 // branch-free: rows q in {1, 2, 5, 6} hold data bins in every lane; elsewhere non-data lanes contribute 0 and
                 // non-writing lanes store to a spare dword behind the image (exec-mask branches cost more than the stores)
                 const bool all_data = !GUARD || q == 1 || q == 2 || q == 5 || q == 6;
-                const bool data = all_data || boff[q] >= 0;
+                const bool data = live && (all_data || boff[q] >= 0); // a dead symbol writes nothing into the image
                 unsigned val = demap_point(v[q], BPS) << (BPS * (s & (32 / BPS - 1)));
                 val = data ? val : 0u;
                 val |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x128, 0xF, 0xF, true);          // row_ror:8   : s ^ 1
@@ -826,8 +833,8 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { // OR every field into the image
-                if (boff[q] >= 0) {
+            for (int q = 0; q < 8; ++q) { // OR every field into the image; a dead symbol (k >= nsym_frame[f]) must leave it clear:
+                if (live && boff[q] >= 0) { // nothing flushes the image after such a step, and demap_point(0) != 0 for BPS >= 2
                     const unsigned idx = demap_point(v[q], BPS);
                     const int wd = boff[q] >> 5, sh = boff[q] & 31;
                     atomicOr(&img[wd], idx << sh);
@@ -860,8 +867,9 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     if (p.total <= 0) return hipSuccess;
     const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64;
     long long grid = (long long)num_cu * 2;
-    if (const char *e = getenv("OFDM_MID_GRID")) { const long long v = atoll(e); if (v > 0 && v < grid) grid = v; } // test hook, as kernels_mid.hip
+    { const long long cap = tuning_or_default(sp.tune).grid_cap; if (cap > 0 && cap < grid) grid = cap; } // test hook, as kernels_mid.hip
     if (grid > p.total) grid = p.total;
+    trace_add(sp.trace, frame ? "k_demod4096<frame>" : "k_demod4096");
     p.step_f = grid / p.syms_per_frame; p.step_k = (int)(grid - p.step_f * p.syms_per_frame);
     // > 64 KB of dynamic LDS: a per-device attribute, so set on every call (one process may drive several GPUs); once per batch
 #define OFDM_LAUNCH_4096_F(B, G, F)                                                                                         \
@@ -1075,7 +1083,9 @@ hipError_t run_rxframe1024(const SymParams &sp, float2 *hk_out, hipStream_t st, 
     p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym = sp.nsym_frame; p.tw = sp.tw; p.inv_training = sp.inv_training;
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.hk = hk_out; p.bps = sp.bps;
     long long grid = (long long)num_cu * 7;
+    { const long long cap = tuning_or_default(sp.tune).grid_cap; if (cap > 0 && cap < grid) grid = cap; }
     if (grid > p.n_frames) grid = p.n_frames;
+    trace_add(sp.trace, "k_rxframe1024");
 #define OFDM_LAUNCH_RX1024(B, G) { hipLaunchKernelGGL((k_rxframe1024<B, G>), dim3((unsigned)grid), dim3(128), 0, st, p); return hipGetLastError(); }
     switch (sp.bps * 2 + (sp.guard ? 1 : 0)) {
     case 2: OFDM_LAUNCH_RX1024(1, false) case 3: OFDM_LAUNCH_RX1024(1, true)
@@ -1221,6 +1231,7 @@ hipError_t run_tx4096(const SymParams &sp, hipStream_t st, int num_cu) {
     const int nd = sp.guard ? 48 * 64 : 4096;
     const int sym_bytes = nd * sp.bps / 8;
     if ((sym_bytes & 3) || sp.payload_stride != sym_bytes || sp.out_stride_s != 5120) return hipErrorNotSupported;
+    if (reinterpret_cast<uintptr_t>(sp.out) & 15) return hipErrorNotSupported; // 16-byte stores
     if (sp.n_frames <= 0) return hipSuccess;
     Tx4096Params p;
     p.bytes = sp.payload; p.n_bytes = sp.tx_raw_total; p.n_sym = sp.n_frames; p.tw = sp.tw; p.out = sp.out; p.bps = sp.bps; p.guard = sp.guard;
@@ -1231,7 +1242,9 @@ hipError_t run_tx4096(const SymParams &sp, hipStream_t st, int num_cu) {
         if (e != hipSuccess) return e;
     }
     long long grid = (long long)num_cu * 2;
+    { const long long cap = tuning_or_default(sp.tune).grid_cap; if (cap > 0 && cap < grid) grid = cap; }
     if (grid > p.n_sym) grid = p.n_sym;
+    trace_add(sp.trace, "k_tx4096");
     if (sp.guard) hipLaunchKernelGGL(k_tx4096<true>, dim3((unsigned)grid), dim3(512), lds, st, p);
     else hipLaunchKernelGGL(k_tx4096<false>, dim3((unsigned)grid), dim3(512), lds, st, p);
     return hipGetLastError();
@@ -1400,8 +1413,9 @@ hipError_t run_txframe4096(const SymParams &sp, const float2 *header, float head
                             : hipFuncSetAttribute(reinterpret_cast<const void *>(k_txframe4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     long long grid = (long long)num_cu * 2;
-    if (const char *e = getenv("OFDM_MID_GRID")) { const long long v = atoll(e); if (v > 0 && v < grid) grid = v; } // test hook, as kernels_mid.hip
+    { const long long cap = tuning_or_default(sp.tune).grid_cap; if (cap > 0 && cap < grid) grid = cap; } // test hook, as kernels_mid.hip
     if (grid > p.n_frames) grid = p.n_frames;
+    trace_add(sp.trace, "k_txframe4096");
     if (sp.guard) hipLaunchKernelGGL(k_txframe4096<true>, dim3((unsigned)grid), dim3(512), lds, st, p);
     else hipLaunchKernelGGL(k_txframe4096<false>, dim3((unsigned)grid), dim3(512), lds, st, p);
     return hipGetLastError();
@@ -1410,39 +1424,46 @@ hipError_t run_txframe4096(const SymParams &sp, const float2 *header, float head
 // Persistent grid: resident workgroups per CU from the occupancy API (per instantiation and device, cached), doubled up
 // to the 8 the round-1 launcher used -- measured (OFDM_DEMOD64_WG_PER_CU sweep, 1 M frames): 3 -> 1.77 ms, 4 -> 1.70,
 // 5 -> 1.81, 8 -> 1.68: a second, queued round of workgroups evens out the tail.
+// The cache is keyed by the kernel's ADDRESS: every k_demod64 instantiation has the same function type, so a static inside a
+// template over that type would be shared by all of them (the BURST = 16 variant holds 37 KB of LDS per workgroup, the others 11).
 template <typename K> static int resident_blocks(K kernel, int block) {
-    static int cached[16] = {0};
+    struct Entry { const void *fn; int dev, n; };
+    static Entry cache[64];
+    static int used = 0;
+    static std::mutex mtx;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (!cached[dev]) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 4;
-        cached[dev] = n > 8 ? 8 : n;
-    }
-    return cached[dev];
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    std::lock_guard<std::mutex> lock(mtx);
+    for (int i = 0; i < used; ++i) if (cache[i].fn == fn && cache[i].dev == dev) return cache[i].n;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 4;
+    n = n > 8 ? 8 : n;
+    if (used < 64) cache[used++] = Entry{fn, dev, n};
+    return n;
 }
-template <int BPS, bool GUARD, bool HK> static hipError_t launch_demod64(Fast64Params p, hipStream_t st, int num_cu) {
-    { static const int dbg = [] { const char *v = getenv("OFDM_DEMOD64_DEBUG"); return v ? atoi(v) : 0; }(); p.debug = dbg; }
+template <int BPS, bool GUARD, bool HK> static hipError_t launch_demod64(Fast64Params p, hipStream_t st, int num_cu, const Tuning &tu, Trace *trace) {
+    p.debug = kProfile ? tu.debug_demod64 : 0;
     constexpr int region_bytes = (GUARD ? 48 : 64) * BPS;
     {   // 16-byte stores need 16-byte aligned group regions: base, frame stride and the 8-symbol region itself
-        static const bool narrow = getenv("OFDM_DEMOD64_NARROW_STORES") != nullptr; // A/B
-        p.wide_stores = !narrow && region_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_stride & 15) == 0;
+        p.wide_stores = !tu.demod64_narrow_stores && region_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_stride & 15) == 0;
     }
     // burst mode (config-2 shape only: the template is instantiated once): 4 groups per step, whole-line stores
-    static const bool no_burst = getenv("OFDM_DEMOD64_NO_BURST") != nullptr; // A/B
-    const bool burst = BPS == 6 && GUARD && !HK && !no_burst && p.wide_stores && p.n_groups % 4 == 0 &&
+    const bool burst = BPS == 6 && GUARD && !HK && tu.demod64_burst >= 4 && p.wide_stores && p.n_groups % 4 == 0 &&
                        p.out_stride == (long long)p.groups_per_frame * region_bytes && (reinterpret_cast<uintptr_t>(p.out) & 127) == 0;
     // 16 groups per burst where the batch divides (4.6 KB of stores per wavefront step; 37 KB of LDS per workgroup still leaves four
-    // resident): 1.784 -> 1.761 ms per 1 M frames against bursts of 4 on a box of the slow population; OFDM_DEMOD64_BURST caps it (A/B)
-    static const int burst_cap = [] { const char *v = getenv("OFDM_DEMOD64_BURST"); const int b = v ? atoi(v) : 16; return (b == 4 || b == 8) ? b : 16; }();
+    // resident): 1.784 -> 1.761 ms per 1 M frames against bursts of 4 on a box of the slow population; Tuning::demod64_burst caps it (A/B)
+    const int burst_cap = tu.demod64_burst;
     const int bl = !burst ? 1 : (burst_cap >= 16 && p.n_groups % 16 == 0) ? 16 : (burst_cap >= 8 && p.n_groups % 8 == 0) ? 8 : 4;
     auto kernel = !burst ? k_demod64<BPS, GUARD, HK, 1> : bl == 16 ? k_demod64<6, true, false, 16> : bl == 8 ? k_demod64<6, true, false, 8> : k_demod64<6, true, false, 4>;
     const long long units = burst ? p.n_groups / bl : p.n_groups;
     long long waves = (units + 3) / 4 * 4;
-    static const int knob = [] { const char *v = getenv("OFDM_DEMOD64_WG_PER_CU"); return v ? atoi(v) : 0; }(); // tuning knob
-    const long long cap = (long long)num_cu * (knob > 0 ? knob : (resident_blocks(kernel, 256) >= 4 ? 8 : 2 * resident_blocks(kernel, 256))) * 4;
+    const int knob = tu.demod64_wg_per_cu; // tuning knob
+    long long cap = (long long)num_cu * (knob > 0 ? knob : (resident_blocks(kernel, 256) >= 4 ? 8 : 2 * resident_blocks(kernel, 256))) * 4;
+    if (tu.grid_cap > 0 && tu.grid_cap * 4 < cap) cap = tu.grid_cap * 4;
     if (waves > cap) waves = cap;
     const int grid = (int)(waves / 4);
+    trace_add(trace, !burst ? "k_demod64" : bl == 16 ? "k_demod64<burst16>" : bl == 8 ? "k_demod64<burst8>" : "k_demod64<burst4>");
     p.stride_groups = (long long)grid * 4;
     const int gpf = p.groups_per_frame;
     p.f0 = 0; p.k0 = 0;
@@ -1452,12 +1473,12 @@ template <int BPS, bool GUARD, bool HK> static hipError_t launch_demod64(Fast64P
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
-template <int BPS> static hipError_t launch_bps(const Fast64Params &p, bool guard, hipStream_t st, int num_cu) {
+template <int BPS> static hipError_t launch_bps(const Fast64Params &p, bool guard, hipStream_t st, int num_cu, const Tuning &tu, Trace *trace) {
     const bool hk = p.hk != nullptr;
-    if (guard && hk) return launch_demod64<BPS, true, true>(p, st, num_cu);
-    if (guard) return launch_demod64<BPS, true, false>(p, st, num_cu);
-    if (hk) return launch_demod64<BPS, false, true>(p, st, num_cu);
-    return launch_demod64<BPS, false, false>(p, st, num_cu);
+    if (guard && hk) return launch_demod64<BPS, true, true>(p, st, num_cu, tu, trace);
+    if (guard) return launch_demod64<BPS, true, false>(p, st, num_cu, tu, trace);
+    if (hk) return launch_demod64<BPS, false, true>(p, st, num_cu, tu, trace);
+    return launch_demod64<BPS, false, false>(p, st, num_cu, tu, trace);
 }
 
 // Returns hipErrorNotSupported when the request is outside the fast path's envelope (caller falls back to k_sym).
@@ -1474,12 +1495,13 @@ hipError_t run_demod64_fast(const SymParams &sp, hipStream_t st, int num_cu) {
     p.groups_per_frame = sp.syms_per_frame / 8;
     p.n_groups = sp.n_frames * (long long)p.groups_per_frame;
     if (p.n_groups <= 0) return hipSuccess;
+    const Tuning &tu = tuning_or_default(sp.tune);
     switch (sp.bps) {
-    case 1: return launch_bps<1>(p, sp.guard != 0, st, num_cu);
-    case 2: return launch_bps<2>(p, sp.guard != 0, st, num_cu);
-    case 4: return launch_bps<4>(p, sp.guard != 0, st, num_cu);
-    case 6: return launch_bps<6>(p, sp.guard != 0, st, num_cu);
-    case 8: return launch_bps<8>(p, sp.guard != 0, st, num_cu);
+    case 1: return launch_bps<1>(p, sp.guard != 0, st, num_cu, tu, sp.trace);
+    case 2: return launch_bps<2>(p, sp.guard != 0, st, num_cu, tu, sp.trace);
+    case 4: return launch_bps<4>(p, sp.guard != 0, st, num_cu, tu, sp.trace);
+    case 6: return launch_bps<6>(p, sp.guard != 0, st, num_cu, tu, sp.trace);
+    case 8: return launch_bps<8>(p, sp.guard != 0, st, num_cu, tu, sp.trace);
     default: return hipErrorNotSupported;
     }
 }

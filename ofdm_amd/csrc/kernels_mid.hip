@@ -296,9 +296,11 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
             for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
         }
         // demodulate (src/receiver.rs:147-190) and pack LSB-first (src/utils.rs:30-36): OR every field into the image
+        // A dead symbol (past the batch, or k >= nsym_frame[f]) must leave the image untouched: nothing flushes (and clears) it
+        // after such a step, and demap_point(0) is not 0 for BPS >= 2 -- stale bits would be OR-ed into the next live symbol.
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (boff[q] >= 0) {
+            if (live && boff[q] >= 0) {
                 const unsigned idx = demap_point(v[q], BPS);
                 const int wd = boff[q] >> 5, sh = boff[q] & 31;
                 atomicOr(&myimg[wd], idx << sh);
@@ -312,19 +314,19 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
     if (pending) flush(pending);
 }
 
-// Persistent grid: OCC resident workgroups per CU (39 KB of LDS each).  OFDM_MID_GRID caps it (test hook: a small
+// Persistent grid: OCC resident workgroups per CU (39 KB of LDS each).  Tuning::grid_cap caps it (test hook: a small
 // grid makes every workgroup run many steps of the prefetch / deferred-store pipeline on a small batch).
-static long long mid_grid(long long steps, int num_cu, int occ) {
+static long long mid_grid(long long steps, int num_cu, int occ, long long cap) {
     long long grid = (long long)num_cu * occ;
-    if (const char *e = getenv("OFDM_MID_GRID")) { const long long v = atoll(e); if (v > 0 && v < grid) grid = v; }
+    if (cap > 0 && cap < grid) grid = cap;
     return grid > steps ? steps : grid;
 }
 
-template <int R, int BPS, bool GUARD> hipError_t launch_demod_mid(const MidRxParams &p0, bool frame, hipStream_t st, int num_cu) {
+template <int R, int BPS, bool GUARD> hipError_t launch_demod_mid(const MidRxParams &p0, bool frame, hipStream_t st, int num_cu, long long cap) {
     MidRxParams p = p0;
     constexpr int G = Mid<R>::G;
     const long long steps = (p.total + G - 1) / G;
-    const long long grid = mid_grid(steps, num_cu, Mid<R>::OCC_RX);
+    const long long grid = mid_grid(steps, num_cu, Mid<R>::OCC_RX, cap);
     const long long adv = grid * G;
     p.step_f = adv / p.syms_per_frame;
     p.step_k = (int)(adv - p.step_f * p.syms_per_frame);
@@ -332,18 +334,18 @@ template <int R, int BPS, bool GUARD> hipError_t launch_demod_mid(const MidRxPar
     else hipLaunchKernelGGL((k_demod_mid<R, BPS, GUARD, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
-template <int R> hipError_t dispatch_demod_mid(const MidRxParams &p, int bps, bool guard, bool frame, hipStream_t st, int num_cu) {
+template <int R> hipError_t dispatch_demod_mid(const MidRxParams &p, int bps, bool guard, bool frame, hipStream_t st, int num_cu, long long cap) {
     switch (bps * 2 + (guard ? 1 : 0)) {
-    case 2: return launch_demod_mid<R, 1, false>(p, frame, st, num_cu);
-    case 3: return launch_demod_mid<R, 1, true>(p, frame, st, num_cu);
-    case 4: return launch_demod_mid<R, 2, false>(p, frame, st, num_cu);
-    case 5: return launch_demod_mid<R, 2, true>(p, frame, st, num_cu);
-    case 8: return launch_demod_mid<R, 4, false>(p, frame, st, num_cu);
-    case 9: return launch_demod_mid<R, 4, true>(p, frame, st, num_cu);
-    case 12: return launch_demod_mid<R, 6, false>(p, frame, st, num_cu);
-    case 13: return launch_demod_mid<R, 6, true>(p, frame, st, num_cu);
-    case 16: return launch_demod_mid<R, 8, false>(p, frame, st, num_cu);
-    case 17: return launch_demod_mid<R, 8, true>(p, frame, st, num_cu);
+    case 2: return launch_demod_mid<R, 1, false>(p, frame, st, num_cu, cap);
+    case 3: return launch_demod_mid<R, 1, true>(p, frame, st, num_cu, cap);
+    case 4: return launch_demod_mid<R, 2, false>(p, frame, st, num_cu, cap);
+    case 5: return launch_demod_mid<R, 2, true>(p, frame, st, num_cu, cap);
+    case 8: return launch_demod_mid<R, 4, false>(p, frame, st, num_cu, cap);
+    case 9: return launch_demod_mid<R, 4, true>(p, frame, st, num_cu, cap);
+    case 12: return launch_demod_mid<R, 6, false>(p, frame, st, num_cu, cap);
+    case 13: return launch_demod_mid<R, 6, true>(p, frame, st, num_cu, cap);
+    case 16: return launch_demod_mid<R, 8, false>(p, frame, st, num_cu, cap);
+    case 17: return launch_demod_mid<R, 8, true>(p, frame, st, num_cu, cap);
     }
     return hipErrorNotSupported;
 }
@@ -488,10 +490,10 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
     }
 }
 
-template <int R> hipError_t launch_tx_mid(const MidTxParams &p, bool guard, hipStream_t st, int num_cu) {
+template <int R> hipError_t launch_tx_mid(const MidTxParams &p, bool guard, hipStream_t st, int num_cu, long long cap) {
     constexpr int G = Mid<R>::G;
     const long long steps = (p.n_sym + G - 1) / G;
-    const long long grid = mid_grid(steps, num_cu, Mid<R>::OCC_TX);
+    const long long grid = mid_grid(steps, num_cu, Mid<R>::OCC_TX, cap);
     if (guard) hipLaunchKernelGGL((k_tx_mid<R, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_tx_mid<R, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     }
 }
 
-template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, hipStream_t st, int num_cu) {
+template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, hipStream_t st, int num_cu, long long cap) {
     constexpr int G = Mid<R>::G;
     // frames per round: the count (<= 8, <= 32 slots' worth) that wastes the fewest symbol slots of the last step
     int best = 1; double waste = 2.0;
@@ -682,7 +684,7 @@ template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, h
     }
     p.fpw = best;
     const long long rounds = (p.n_frames + p.fpw - 1) / p.fpw;
-    const long long grid = mid_grid(rounds, num_cu, 3); // built for 3 waves per SIMD: the twice-inlined symbol builder spills at 4
+    const long long grid = mid_grid(rounds, num_cu, 3, cap); // built for 3 waves per SIMD: the twice-inlined symbol builder spills at 4
     if (guard) hipLaunchKernelGGL((k_txframe_mid<R, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_txframe_mid<R, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();
@@ -707,12 +709,14 @@ hipError_t run_demod_mid(int n_fft, const SymParams &sp, hipStream_t st, int num
     p.tw = sp.tw; p.hk = sp.hk; p.hk_stride = sp.hk_stride; p.out = sp.out_bytes; p.out_stride = sp.out_stride;
     p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym_frame = sp.nsym_frame; p.frame_len = sp.frame_len;
     if (p.total <= 0) return hipSuccess;
+    const long long cap = tuning_or_default(sp.tune).grid_cap;
+    trace_add(sp.trace, frame ? "k_demod_mid<frame>" : "k_demod_mid");
     switch (R) {
-    case 2: return dispatch_demod_mid<2>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
-    case 4: return dispatch_demod_mid<4>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
-    case 8: return dispatch_demod_mid<8>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
-    case 16: return dispatch_demod_mid<16>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
-    case 32: return dispatch_demod_mid<32>(p, sp.bps, sp.guard != 0, frame, st, num_cu);
+    case 2: return dispatch_demod_mid<2>(p, sp.bps, sp.guard != 0, frame, st, num_cu, cap);
+    case 4: return dispatch_demod_mid<4>(p, sp.bps, sp.guard != 0, frame, st, num_cu, cap);
+    case 8: return dispatch_demod_mid<8>(p, sp.bps, sp.guard != 0, frame, st, num_cu, cap);
+    case 16: return dispatch_demod_mid<16>(p, sp.bps, sp.guard != 0, frame, st, num_cu, cap);
+    case 32: return dispatch_demod_mid<32>(p, sp.bps, sp.guard != 0, frame, st, num_cu, cap);
     }
     return hipErrorNotSupported;
 }
@@ -730,13 +734,15 @@ hipError_t run_tx_mid(int n_fft, const SymParams &sp, hipStream_t st, int num_cu
     if (sp.n_frames <= 0) return hipSuccess;
     MidTxParams p;
     p.bytes = sp.payload; p.n_bytes = sp.tx_raw_total; p.n_sym = sp.n_frames; p.tw = sp.tw; p.out = sp.out; p.bps = sp.bps;
+    const long long cap = tuning_or_default(sp.tune).grid_cap;
+    trace_add(sp.trace, "k_tx_mid");
     switch (R) {
-    case 1: return launch_tx_mid<1>(p, sp.guard != 0, st, num_cu);
-    case 2: return launch_tx_mid<2>(p, sp.guard != 0, st, num_cu);
-    case 4: return launch_tx_mid<4>(p, sp.guard != 0, st, num_cu);
-    case 8: return launch_tx_mid<8>(p, sp.guard != 0, st, num_cu);
-    case 16: return launch_tx_mid<16>(p, sp.guard != 0, st, num_cu);
-    case 32: return launch_tx_mid<32>(p, sp.guard != 0, st, num_cu);
+    case 1: return launch_tx_mid<1>(p, sp.guard != 0, st, num_cu, cap);
+    case 2: return launch_tx_mid<2>(p, sp.guard != 0, st, num_cu, cap);
+    case 4: return launch_tx_mid<4>(p, sp.guard != 0, st, num_cu, cap);
+    case 8: return launch_tx_mid<8>(p, sp.guard != 0, st, num_cu, cap);
+    case 16: return launch_tx_mid<16>(p, sp.guard != 0, st, num_cu, cap);
+    case 32: return launch_tx_mid<32>(p, sp.guard != 0, st, num_cu, cap);
     }
     return hipErrorNotSupported;
 }
@@ -753,13 +759,15 @@ hipError_t run_txframe_mid(int n_fft, const SymParams &sp, const float2 *header,
     p.payload = sp.payload; p.payload_stride = sp.payload_stride; p.payload_len = sp.payload_len; p.payload_bytes = sp.payload_bytes;
     p.n_frames = sp.n_frames; p.D = sp.syms_per_frame; p.fpw = 1; p.tw = sp.tw; p.header = header; p.header_max = header_max;
     p.out = sp.out; p.out_stride = sp.out_stride_s; p.bps = sp.bps;
+    const long long cap = tuning_or_default(sp.tune).grid_cap;
+    trace_add(sp.trace, "k_txframe_mid");
     switch (R) {
-    case 1: return launch_txframe_mid<1>(p, sp.guard != 0, st, num_cu);
-    case 2: return launch_txframe_mid<2>(p, sp.guard != 0, st, num_cu);
-    case 4: return launch_txframe_mid<4>(p, sp.guard != 0, st, num_cu);
-    case 8: return launch_txframe_mid<8>(p, sp.guard != 0, st, num_cu);
-    case 16: return launch_txframe_mid<16>(p, sp.guard != 0, st, num_cu);
-    case 32: return launch_txframe_mid<32>(p, sp.guard != 0, st, num_cu);
+    case 1: return launch_txframe_mid<1>(p, sp.guard != 0, st, num_cu, cap);
+    case 2: return launch_txframe_mid<2>(p, sp.guard != 0, st, num_cu, cap);
+    case 4: return launch_txframe_mid<4>(p, sp.guard != 0, st, num_cu, cap);
+    case 8: return launch_txframe_mid<8>(p, sp.guard != 0, st, num_cu, cap);
+    case 16: return launch_txframe_mid<16>(p, sp.guard != 0, st, num_cu, cap);
+    case 32: return launch_txframe_mid<32>(p, sp.guard != 0, st, num_cu, cap);
     }
     return hipErrorNotSupported;
 }

@@ -387,7 +387,8 @@ hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_
     q.L = p.L; q.W = p.W; q.C = p.L / 8; q.threshold = p.threshold;
     q.nch = (int)((p.n_lags + p.W + p.L + q.C - 1) / q.C + 1);
     q.nch_pad = (q.nch + 1 + 7) / 8 * 8;
-    const bool contig = p.L <= 1280 && getenv("OFDM_SCB_TWO_SEGMENTS") == nullptr; // the partner sample fits the same LDS image
+    const Tuning &tu = tuning_or_default(p.tune);
+    const bool contig = p.L <= 1280 && !tu.scb_two_segments; // the partner sample fits the same LDS image
     const int tile = contig ? 2 * B_TILE : B_TILE;
     q.tiles_per_frame = (int)(((long long)q.nch * q.C + tile - 1) / tile);
     q.ws = reinterpret_cast<double *>(workspace);
@@ -395,8 +396,10 @@ hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_
     const long long items = p.n_frames * (long long)q.tiles_per_frame;
     const size_t lds1 = contig ? (size_t)(2 * B_TILE + p.L) * sizeof(float2) : (size_t)2 * B_TILE * sizeof(float2);
     long long g1 = (long long)num_cu * ((long long)(160 * 1024) / (long long)lds1);
+    if (tu.grid_cap > 0 && g1 > tu.grid_cap) g1 = tu.grid_cap;
     if (g1 > items) g1 = items;
     hipError_t e;
+    trace_add(p.trace, contig ? "k_scb_chunks<contig>" : "k_scb_chunks");
     if (contig) {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scb_chunks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_scb_chunks<true>, dim3((unsigned)g1), dim3(256), lds1, st, q);
@@ -406,7 +409,7 @@ hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_
     // Tiles start at chunk boundaries, so a tile is a whole number of chunks: 320-lag tiles (5 lags per thread) where C <= 320
     // (N <= 2048), 640-lag tiles for N = 4096.  The small tile halves the LDS and the registers of a frame (12 instead of 7
     // frames in flight per CU) at twice the number of tiles.
-    const bool small = q.C <= 320 && (320 % q.C) == 0 && getenv("OFDM_SCB_BIG_TILES") == nullptr;
+    const bool small = q.C <= 320 && (320 % q.C) == 0 && !tu.scb_big_tiles;
     const int f_tile = small ? 5 * F_WG : 10 * F_WG;
     const size_t lds = (size_t)4 * (f_tile + 16) * sizeof(float2) + (size_t)q.nch_pad * sizeof(float) + 2 * sizeof(BSums) +
                        2 * sizeof(BCand) + 4 * sizeof(int) + 64;
@@ -414,7 +417,9 @@ hipError_t run_sc_big(const ScParams &p, void *workspace, int num_cu, hipStream_
     const long long cap = small ? 12 : 8; // 3 / 2 waves per SIMD (163 / 236 VGPRs; 4 waves spill 22 registers for +2 %)
     if (per_cu > cap) per_cu = cap;
     long long g2 = (long long)num_cu * per_cu;
+    if (tu.grid_cap > 0 && g2 > tu.grid_cap) g2 = tu.grid_cap;
     if (g2 > p.n_frames) g2 = p.n_frames;
+    trace_add(p.trace, small ? "k_scb_fine<5>" : "k_scb_fine<10>");
     if (small) hipLaunchKernelGGL(k_scb_fine<5>, dim3((unsigned)g2), dim3(F_WG), lds, st, q);
     else hipLaunchKernelGGL(k_scb_fine<10>, dim3((unsigned)g2), dim3(F_WG), lds, st, q);
     return hipGetLastError();

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
             if (live) {
                 const int nbytes = nd * p.bps / 8;
                 unsigned char *dst = p.out_bytes + f * p.out_stride + (long long)k * nbytes;
-                if ((nbytes & 3) == 0 && ((p.out_stride & 3) == 0)) {
+                if ((nbytes & 3) == 0 && (p.out_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out_bytes) & 3) == 0) {
                     for (int wd = t; wd < nbytes / 4; wd += T) {
                         unsigned acc = 0;
                         int i = (32 * wd) / p.bps;
@@ -348,6 +348,8 @@ template <int N, int MODE> static hipError_t launch_sym(const SymParams &p, hipS
     long long groups = (total + P::G - 1) / P::G;
     long long cap = (long long)num_cu * 8; // persistent: ~8 workgroups per CU, grid-stride over symbol groups
     int grid = (int)(groups < cap ? groups : cap);
+    static const char *const names[] = {"k_sym<fft>", "k_sym<ifft>", "k_sym<ifft_cp>", "k_sym<demod>", "k_sym<chest>", "k_sym<tx>"};
+    trace_add(p.trace, names[MODE]);
     hipLaunchKernelGGL((k_sym<N, MODE>), dim3(grid), dim3(P::WG), 0, st, p);
     return hipGetLastError();
 }

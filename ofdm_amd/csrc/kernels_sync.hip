@@ -208,6 +208,7 @@ hipError_t run_sc(const ScParams &p, hipStream_t st) {
     }
     long long blocks = p.n_frames * (long long)p.tiles_per_frame;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    trace_add(p.trace, p.mode == 0 ? "k_sc_tile" : p.mode == 1 ? "k_sc_tile<cross>" : "k_sc_tile<peak>");
     hipLaunchKernelGGL(k_sc_tile, dim3((unsigned)blocks), dim3(SC_WG), lds, st, p);
     return hipGetLastError();
 }
@@ -302,7 +303,7 @@ struct ScFastParams {
     long long n_frames, frame_stride;
     int n16;        // 16-byte pieces to stage per frame = min(10 NCH, frame_len) / 2
     int n_lags, L, W;
-    int debug;      // profiling aid (OFDM_SC_DEBUG): 2 / 3 / 5 / 4 stop after phase 1 / coarse / slide / select; 10..17 section times
+    int debug;      // profiling aid (Tuning::debug_sc, profile build only): 2 / 3 / 5 / 4 stop after phase 1 / coarse / slide / select; 10..17 section times
     float thr_lo, thr_hi;
     int32_t *d_hat;
     int32_t *slow_list; // frames the filter could not settle
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
     constexpr int ND = GUARD ? 48 : 64, SYM_BYTES = ND * (RX ? BPS : 8) / 8, REGION_DW = 2 * SYM_BYTES; // 8 symbols, in dwords
     extern __shared__ __align__(16) unsigned char smem[];
     const int L = RX ? 80 : p.L, W = p.W, n = p.n_lags;
+    const int dbg = kProfile ? p.debug : 0; // the early exits / section ticks exist in the profile build only
     const int nstaged = 2 * p.n16;
     const int ns = (nstaged + C - 1) / C * C;               // whole 10-sample chunks
     cf *raw = reinterpret_cast<cf *>(smem);                 // [ns + L]; entries past the staged samples stay 0
@@ -490,10 +492,10 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
     int it = blockIdx.x;
 
     for (; f < p.n_frames; f += fstep, ++it) {
-        const long long t0 = (p.debug >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long t0 = (dbg >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
         lds_barrier();                                   // B0: ... and everyone else's
-        const long long t1 = (p.debug >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long t1 = (dbg >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const bool more = f + fstep < p.n_frames;
         // ---- phase 1 (f32): chunk totals of q and e; exclusive prefixes WITHIN each virtual wavefront (64 chunks) go to
         //      LDS together with the wavefront totals.  A prefix difference that crosses into the next virtual wavefront
@@ -522,8 +524,8 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
             if (lane == 63) { const int vw = u * NW + wave; wtot[vw * 4 + 0] = iqr; wtot[vw * 4 + 1] = iqi; wtot[vw * 4 + 2] = ie; }
         }
         lds_barrier(); // B3: chunk prefixes, energies and wavefront totals visible
-        const long long t2 = t1, t3 = (p.debug >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        if (!RX && p.debug == 2) { lds_barrier(); if (more) stage(f + fstep); continue; }
+        const long long t2 = t1, t3 = (dbg >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        if (!RX && dbg == 2) { lds_barrier(); if (more) stage(f + fstep); continue; }
         float etot = 0.f; // frame energy: bounds every prefix (error margin of the coarse bound)
 #pragma unroll
         for (int wv = 0; wv < VW; ++wv) etot += wtot[wv * 4 + 2];
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
             if (lane == 0) flg[u * NW + wave] = fm;
         }
         lds_barrier(); // B4: flags visible
-        const long long t4 = (p.debug >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long t4 = (dbg >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         unsigned long long fmask[VW];
 #pragma unroll
         for (int wv = 0; wv < VW; ++wv) {
@@ -578,14 +580,14 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
             if (more) stage(f + fstep);   // every wave is done with the raw samples (phase 1 ended before B3)
             continue;
         }
-        if (!RX && p.debug == 3) { lds_barrier(); if (more) stage(f + fstep); continue; }
+        if (!RX && dbg == 3) { lds_barrier(); if (more) stage(f + fstep); continue; }
 
         // ---- fine pass: one wavefront, the 32 chunks (320 lags) from the first flagged one; lane 2k slides forward from
         //      chunk boundary k over lags +0..+4, lane 2k+1 slides BACKWARD from boundary k+1 over lags +9..+5
         if (wave == (it & (NW - 1))) {
             const int hh = lane & 1;
             const float sgn = hh ? -1.f : 1.f;
-            long long u0 = (!RX && p.debug >= 15) ? (long long)__builtin_amdgcn_s_memtime() : 0, u1 = 0, u2 = 0;
+            long long u0 = (!RX && dbg >= 15) ? (long long)__builtin_amdgcn_s_memtime() : 0, u1 = 0, u2 = 0;
             int res_d = -1;          // wave-uniform outcome: lag >= 0, -1 no packet, -2 slow list, -3 debug exit
             Cand best = Cand{0.0, 1.0, 1.0, 0.0, INT_MAX};
             for (;;) {
@@ -642,8 +644,8 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                         }
                     }
                 }
-                if (!RX && p.debug == 5) { res_d = -3; break; }
-                if (!RX && p.debug >= 15) u1 = (long long)__builtin_amdgcn_s_memtime();
+                if (!RX && dbg == 5) { res_d = -3; break; }
+                if (!RX && dbg >= 15) u1 = (long long)__builtin_amdgcn_s_memtime();
                 const unsigned long long lo_m = __ballot(lo != INT_MAX), hi_m = __ballot(hi != INT_MAX);
                 if (lo_m == 0) { // nothing crosses in these 32 chunks: on to the next flagged chunk
                     gs = next_flag(gs + 32);
@@ -685,8 +687,8 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                 }
                 if (cnt == 0) { res_d = -1; break; }
                 if (cnt > SC_MAXCAND) { res_d = -2; break; }
-                if (!RX && p.debug == 4) { res_d = -3; break; }
-                if (!RX && p.debug >= 15) u2 = (long long)__builtin_amdgcn_s_memtime();
+                if (!RX && dbg == 4) { res_d = -3; break; }
+                if (!RX && dbg >= 15) u2 = (long long)__builtin_amdgcn_s_memtime();
                 best = sc_exact_pick(raw, cand[0], cand[1], cand[2], cand[3], cnt, L, W, lane);
                 res_d = best.lag != INT_MAX ? best.lag : -1;
                 break;
@@ -700,9 +702,9 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                         else p.exact[f] = ScExact{0.0, 0.0, 0.0, 1.0};
                     }
                 }
-                if (p.debug >= 15 && lane == 0) { // profiling aid: slide / select / exact time of the fine wavefront
+                if (dbg >= 15 && lane == 0) { // profiling aid: slide / select / exact time of the fine wavefront
                     const long long u3 = (long long)__builtin_amdgcn_s_memtime();
-                    p.d_hat[f] = (int32_t)(p.debug == 15 ? u1 - u0 : p.debug == 16 ? u2 - u1 : u3 - u2);
+                    p.d_hat[f] = (int32_t)(dbg == 15 ? u1 - u0 : dbg == 16 ? u2 - u1 : u3 - u2);
                 }
             } else if (res_d == -2) {
                 if (lane == 0) { to_slow(f); sh_i[0] = 1; }
@@ -738,15 +740,15 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
         }
         lds_barrier(); // B5: the fine wavefront is done with the raw samples (RX: scalars and 1/H are in LDS)
         if (!RX) {
-            if (p.debug >= 10 && p.debug < 15 && tid == 0) { // profiling aid: per-frame section time (s_memtime ticks) instead of the timing result
+            if (dbg >= 10 && dbg < 15 && tid == 0) { // profiling aid: per-frame section time (s_memtime ticks) instead of the timing result
                 const long long t5 = (long long)__builtin_amdgcn_s_memtime();
                 const long long dt[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4};
-                p.d_hat[f] = (int32_t)dt[p.debug - 10 < 5 ? p.debug - 10 : 4];
+                p.d_hat[f] = (int32_t)dt[dbg - 10 < 5 ? dbg - 10 : 4];
             }
             if (more) stage(f + fstep);
             continue;
         }
-        const long long t5 = (p.debug >= 20) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long t5 = (dbg >= 20) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         // ---- receive body.  Both wavefronts estimate the channel (cheap: ONE transform per frame), then wavefront w takes
         //      the groups w, w + NW, ... of 8 data symbols
         const int st_f = __builtin_amdgcn_readfirstlane(sh_i[0]);
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
             }
         }
         lds_barrier(); // B6: the packed image is complete; nobody reads the raw samples any more
-        const long long t6 = (p.debug >= 20) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const long long t6 = (dbg >= 20) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (more) stage(f + fstep);                                  // next frame's DMA flies while this one is finished
         for (int i = nstaged + tid; i < ns + L; i += WG) raw[i] = make_float2(0.f, 0.f); // a tail symbol's slab may have spilled into the zero pad
         if (st_f == 0) { // ---- length header, truncate (receiver.rs:85-95) [, Hamming(7,4)], bytes to their final place
@@ -878,10 +880,10 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                 if (tid == 0) p.rx.out_len[f] = blocks * 4;
             }
         } else if (st_f < 0 && tid == 0) p.rx.out_len[f] = 0;
-        if (p.debug >= 20 && tid == 0 && p.rx.metric) { // profiling aid (OFDM_SC_DEBUG=20..26): section ticks instead of the metric
+        if (dbg >= 20 && tid == 0 && p.rx.metric) { // profiling aid (OFDM_SC_DEBUG=20..26): section ticks instead of the metric
             const long long t7 = (long long)__builtin_amdgcn_s_memtime();
             const long long dt[7] = {t1 - t0, t3 - t1, t4 - t3, t5 - t4, t6 - t5, t7 - t6, t7 - t0};
-            p.rx.metric[f] = (float)dt[p.debug - 20 < 7 ? p.debug - 20 : 6];
+            p.rx.metric[f] = (float)dt[dbg - 20 < 7 ? dbg - 20 : 6];
         }
     }
 }
@@ -945,7 +947,8 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     if (needed < stage && !rx) stage = needed;                        // bounded searches stage (and sum) only what they use
     q.n16 = (int)(stage / 2);
     q.n_lags = (int)p.n_lags; q.L = p.L; q.W = p.W;
-    { const char *dbg = getenv("OFDM_SC_DEBUG"); q.debug = dbg ? atoi(dbg) : 0; }
+    const Tuning &tu = tuning_or_default(p.tune);
+    q.debug = kProfile ? tu.debug_sc : 0;
     q.thr_lo = (float)(p.threshold * (1.0 - (double)SC_EPS));
     q.thr_hi = (float)(p.threshold * (1.0 + (double)SC_EPS));
     q.d_hat = p.d_hat; q.slow_list = slow_list; q.slow_count = slow_count; q.exact = exact;
@@ -956,15 +959,18 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         q.rx.offset = rx->offset; q.rx.f_delta = rx->f_delta; q.rx.metric = rx->metric;
     }
     // persistent over the frames; workgroups per CU bounded by LDS (22.5 KB for a 2176-sample frame -> 7)
-    static const int per_cu_cap = [] { const char *v = getenv("OFDM_SC_WG_PER_CU"); return v ? atoi(v) : 7; }(); // tuning knob
+    const int per_cu_cap = tu.sc_wg_per_cu > 0 ? tu.sc_wg_per_cu : 7; // tuning knob
     const size_t lds = sc_cf_lds_bytes(p.L, nch, stage, rx != nullptr);
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
     if (per_cu > per_cu_cap) per_cu = per_cu_cap;
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)num_cu * per_cu;
+    const long long gcap = tu.grid_cap > 0 ? tu.grid_cap : (1LL << 40);
+    if (grid > gcap) grid = gcap;
     if (grid > p.n_frames) grid = p.n_frames;
     if (rx) {
-        if (per_cu > 6) { per_cu = 6; grid = (long long)num_cu * per_cu; if (grid > p.n_frames) grid = p.n_frames; } // 3 waves per SIMD
+        if (per_cu > 6) { per_cu = 6; grid = (long long)num_cu * per_cu; if (grid > gcap) grid = gcap; if (grid > p.n_frames) grid = p.n_frames; } // 3 waves per SIMD
+        trace_add(p.trace, "k_sc_cf<rx>");
         switch (rx->bps) {
         case 1: launch_sc_rx<1>(rx->guard != 0, dim3((unsigned)grid), lds, st, q); break;
         case 2: launch_sc_rx<2>(rx->guard != 0, dim3((unsigned)grid), lds, st, q); break;
@@ -973,12 +979,16 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         case 8: launch_sc_rx<8>(rx->guard != 0, dim3((unsigned)grid), lds, st, q); break;
         default: return hipErrorInvalidValue;
         }
-    } else if (nch == 256) hipLaunchKernelGGL((k_sc_cf<256, 2, 4, 0, false>), dim3((unsigned)grid), dim3(128), lds, st, q); // <= 7 x 2 waves per CU
-    else { // 128-chunk tile (bounded searches): 128 threads, one chunk each, up to 10 workgroups per CU (measured best)
+    } else if (nch == 256) {
+        trace_add(p.trace, "k_sc_cf<256>");
+        hipLaunchKernelGGL((k_sc_cf<256, 2, 4, 0, false>), dim3((unsigned)grid), dim3(128), lds, st, q); // <= 7 x 2 waves per CU
+    } else { // 128-chunk tile (bounded searches): 128 threads, one chunk each, up to 10 workgroups per CU (measured best)
         per_cu = (long long)(160 * 1024) / (long long)lds;
         if (per_cu > 10) per_cu = 10;
         grid = (long long)num_cu * per_cu;
+        if (grid > gcap) grid = gcap;
         if (grid > p.n_frames) grid = p.n_frames;
+        trace_add(p.trace, "k_sc_cf<128>");
         hipLaunchKernelGGL((k_sc_cf<128, 1, 5, 0, false>), dim3((unsigned)grid), dim3(128), lds, st, q);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -996,6 +1006,7 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         if (e != hipSuccess) return e;
     }
     long long g2 = p.n_frames < 512 ? p.n_frames : 512;
+    trace_add(p.trace, "k_sc_tile<list>");
     hipLaunchKernelGGL(k_sc_tile, dim3((unsigned)g2), dim3(SC_WG), lds2, st, s);
     return hipGetLastError();
 }

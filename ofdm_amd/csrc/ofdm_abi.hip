@@ -76,6 +76,8 @@ struct ofdm_ctx {
     float2 *d_header = nullptr;   // 10 * S un-normalised header samples
     double *d_atan_tab = nullptr; // 32 x (cos, sin)(k pi / 16): the fused receive kernel's f64 atan2 (kernels_sync.hip)
     float header_max = 0.f;
+    Tuning tune;                  // ofdm_set_tuning: per-context A/B switches and grid shapes (no environment variable is read)
+    Trace trace;                  // ofdm_last_dispatch: the kernels the last entry point launched
     // workspaces (grown on demand, never inside a captured region)
     Workspace ws[8];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -117,8 +119,10 @@ static int ws_get(ofdm_ctx *c, int slot, size_t bytes, void **out) {
     return OFDM_OK;
 }
 
-static SymParams base_params(const ofdm_ctx *c) {
+static SymParams base_params(ofdm_ctx *c) {
     SymParams p;
+    p.tune = &c->tune;
+    p.trace = &c->trace;
     p.tw = c->d_tw;
     p.inv_training = c->d_inv_trn;
     p.sym_len = c->S();
@@ -307,6 +311,7 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
     if (p->cfo_mode < OFDM_CFO_OFF || p->cfo_mode > OFDM_CFO_ABS) return OFDM_ERR_INVALID;
     if (!(p->sync_threshold > 0.f && p->sync_threshold <= 1.f)) return OFDM_ERR_INVALID;
     if (p->sync_mode != OFDM_SYNC_SCHMIDL_COX && p->sync_mode != OFDM_SYNC_REFERENCE) return OFDM_ERR_INVALID;
+    if (p->rx_path < OFDM_RX_AUTO || p->rx_path > OFDM_RX_ONE_PASS) return OFDM_ERR_INVALID;
     for (int r : p->reserved) if (r != 0) return OFDM_ERR_INVALID;
 
     int ndev = 0;
@@ -321,6 +326,9 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
     if (!c) return OFDM_ERR_NOMEM;
     c->prm = *p;
     c->device = device;
+    c->trace.reset();
+    // AUTO = the staged chain: measured on MI355X it still beats the one-pass kernel by a few per cent
+    c->tune.one_pass_rx = p->rx_path == OFDM_RX_ONE_PASS;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc = OFDM_OK;
     do {
@@ -390,6 +398,57 @@ int ofdm_synchronize(ofdm_ctx *c) {
 }
 int ofdm_last_hip_error(const ofdm_ctx *c) { return c ? c->last_hip : 0; }
 
+namespace {
+struct TuneKey { const char *name; int Tuning::*field; bool profile_only; };
+const TuneKey kTuneKeys[] = {
+    {"one_pass_rx", &Tuning::one_pass_rx, false},
+    {"no_sc_big", &Tuning::no_sc_big, false},
+    {"no_fast64", &Tuning::no_fast64, false},
+    {"no_demod4096", &Tuning::no_demod4096, false},
+    {"no_mid_kernels", &Tuning::no_mid_kernels, false},
+    {"no_rxframe1024", &Tuning::no_rxframe1024, false},
+    {"no_txframe64", &Tuning::no_txframe64, false},
+    {"tx_waves", &Tuning::tx_waves, false},
+    {"sc_wg_per_cu", &Tuning::sc_wg_per_cu, false},
+    {"demod64_wg_per_cu", &Tuning::demod64_wg_per_cu, false},
+    {"demod64_burst", &Tuning::demod64_burst, false},
+    {"demod64_narrow_stores", &Tuning::demod64_narrow_stores, false},
+    {"scb_two_segments", &Tuning::scb_two_segments, false},
+    {"scb_big_tiles", &Tuning::scb_big_tiles, false},
+    {"debug_demod64", &Tuning::debug_demod64, true},
+    {"debug_sc", &Tuning::debug_sc, true},
+    {"debug_tx", &Tuning::debug_tx, true},
+};
+} // namespace
+
+int ofdm_set_tuning(ofdm_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) return OFDM_ERR_INVALID;
+    if (std::strcmp(key, "grid_cap") == 0) { if (value < 0) return OFDM_ERR_INVALID; c->tune.grid_cap = value; return OFDM_OK; }
+    for (const TuneKey &k : kTuneKeys)
+        if (std::strcmp(key, k.name) == 0) {
+            if (k.profile_only && !kProfile) return OFDM_ERR_UNSUPPORTED; // the ablation branches are not in this build
+            if (value < 0 || value > 0x7fffffff) return OFDM_ERR_INVALID;
+            c->tune.*(k.field) = (int)value;
+            return OFDM_OK;
+        }
+    return OFDM_ERR_INVALID;
+}
+int ofdm_get_tuning(const ofdm_ctx *c, const char *key, int64_t *value) {
+    if (!c || !key || !value) return OFDM_ERR_INVALID;
+    if (std::strcmp(key, "grid_cap") == 0) { *value = c->tune.grid_cap; return OFDM_OK; }
+    if (std::strcmp(key, "profile_build") == 0) { *value = kProfile ? 1 : 0; return OFDM_OK; }
+    for (const TuneKey &k : kTuneKeys)
+        if (std::strcmp(key, k.name) == 0) { *value = c->tune.*(k.field); return OFDM_OK; }
+    return OFDM_ERR_INVALID;
+}
+int ofdm_last_dispatch(const ofdm_ctx *c, char *buf, size_t n) {
+    if (!c || !buf || !n) return OFDM_ERR_INVALID;
+    const size_t len = (size_t)c->trace.len < n - 1 ? (size_t)c->trace.len : n - 1;
+    std::memcpy(buf, c->trace.buf, len);
+    buf[len] = 0;
+    return (int)c->trace.len; // the full length, like snprintf
+}
+
 int ofdm_dev_alloc(ofdm_ctx *c, size_t bytes, void **dev) {
     if (!c || !dev) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
@@ -444,6 +503,7 @@ int64_t ofdm_frame_samples(const ofdm_ctx *c, int64_t payload_bytes) {
 int ofdm_fft_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_t n_vec, int inverse) {
     if (!c || n_vec < 0 || (n_vec && (!in || !out))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     SymParams p = base_params(c);
     const int N = c->prm.n_fft;
     p.in = reinterpret_cast<const float2 *>(in); p.out = reinterpret_cast<float2 *>(out);
@@ -454,6 +514,7 @@ int ofdm_fft_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_t n_v
 int ofdm_ifft_cp_batch(ofdm_ctx *c, const ofdm_fc32 *freq, ofdm_fc32 *out, int64_t n_sym) {
     if (!c || n_sym < 0 || (n_sym && (!freq || !out))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     SymParams p = base_params(c);
     const int N = c->prm.n_fft;
     p.in = reinterpret_cast<const float2 *>(freq); p.out = reinterpret_cast<float2 *>(out);
@@ -467,20 +528,19 @@ int ofdm_tx_symbols_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, of
     if (n_sym * (int64_t)bps_bytes < n_bytes) return OFDM_ERR_INVALID; // every byte must land in a symbol
     if (!n_sym) return OFDM_OK;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     SymParams p = base_params(c);
     p.n_frames = n_sym; p.syms_per_frame = 1;
     p.payload = bytes; p.payload_stride = bps_bytes; p.payload_len = nullptr; p.payload_bytes = bps_bytes;
     p.tx_raw_total = n_bytes;
     p.out = reinterpret_cast<float2 *>(out); p.out_stride_s = c->S(); p.frame_max = nullptr;
     if (c->prm.n_fft == 4096) { // 64 x 64 two-stage kernel (kernels_fast.hip)
-        static const bool off = getenv("OFDM_NO_DEMOD4096") != nullptr; // A/B switch shared with the RX side
-        hipError_t e = off ? hipErrorNotSupported : run_tx4096(p, c->stream, c->num_cu);
+        hipError_t e = c->tune.no_demod4096 ? hipErrorNotSupported : run_tx4096(p, c->stream, c->num_cu); // A/B switch shared with the RX side
         if (e == hipSuccess) return OFDM_OK;
         if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
     if (c->prm.n_fft < 4096) { // R x 64 two-stage kernels (kernels_mid.hip; N = 64 is the one-row case)
-        static const bool off = getenv("OFDM_NO_MID_KERNELS") != nullptr;
-        hipError_t e = off ? hipErrorNotSupported : run_tx_mid(c->prm.n_fft, p, c->stream, c->num_cu);
+        hipError_t e = c->tune.no_mid_kernels ? hipErrorNotSupported : run_tx_mid(c->prm.n_fft, p, c->stream, c->num_cu);
         if (e == hipSuccess) return OFDM_OK;
         if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
@@ -490,6 +550,7 @@ int ofdm_tx_symbols_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, of
 int ofdm_unprefix_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_t n_sym) {
     if (!c || n_sym < 0 || (n_sym && (!in || !out))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     SymParams p = base_params(c);
     const int N = c->prm.n_fft, S = c->S();
     p.in = reinterpret_cast<const float2 *>(in); p.out = reinterpret_cast<float2 *>(out);
@@ -500,6 +561,7 @@ int ofdm_unprefix_batch(ofdm_ctx *c, const ofdm_fc32 *in, ofdm_fc32 *out, int64_
 int ofdm_qam_map_batch(ofdm_ctx *c, const uint8_t *bytes, int64_t n_bytes, ofdm_fc32 *out) {
     if (!c || n_bytes < 0 || (n_bytes && (!bytes || !out))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     HIP_TRY(c, run_qam_map(bytes, n_bytes, c->prm.modulation, reinterpret_cast<float2 *>(out), c->stream));
     return OFDM_OK;
 }
@@ -507,12 +569,14 @@ int ofdm_qam_demap_batch(ofdm_ctx *c, const ofdm_fc32 *sym, int64_t n_sym, uint8
     if (!c || n_sym < 0 || (n_sym && !sym)) return OFDM_ERR_INVALID;
     if (n_sym % 8 != 0) return OFDM_ERR_INVALID; // assert_eq!(remainder.len(), 0), src/receiver.rs:153
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     HIP_TRY(c, run_qam_demap(reinterpret_cast<const float2 *>(sym), n_sym, c->prm.modulation, bytes, idx, c->stream));
     return OFDM_OK;
 }
 int ofdm_encode_block_batch(ofdm_ctx *c, const ofdm_fc32 *data, ofdm_fc32 *bins, int64_t n_sym) {
     if (!c || n_sym < 0 || (n_sym && (!data || !bins))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     HIP_TRY(c, run_encode_block(reinterpret_cast<const float2 *>(data), reinterpret_cast<float2 *>(bins), n_sym,
                                 c->prm.n_fft, c->prm.guard_bands, c->stream));
     return OFDM_OK;
@@ -520,6 +584,7 @@ int ofdm_encode_block_batch(ofdm_ctx *c, const ofdm_fc32 *data, ofdm_fc32 *bins,
 int ofdm_normalize_batch(ofdm_ctx *c, ofdm_fc32 *x, int64_t n_frames, int64_t frame_stride, int64_t frame_len) {
     if (!c || n_frames < 0 || frame_len < 0 || frame_stride < frame_len || (n_frames && !x)) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     if (!n_frames) return OFDM_OK;
     void *mx;
     int rc = ws_get(c, 0, sizeof(unsigned) * (size_t)n_frames, &mx);
@@ -532,18 +597,20 @@ int ofdm_normalize_batch(ofdm_ctx *c, ofdm_fc32 *x, int64_t n_frames, int64_t fr
 int ofdm_hamming74_encode(ofdm_ctx *c, const uint8_t *in, int64_t n_bytes, uint8_t *out) {
     if (!c || n_bytes < 0 || (n_bytes && (!in || !out))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     HIP_TRY(c, run_ham_encode(in, 1, 0, nullptr, n_bytes, out, 0, nullptr, c->stream));
     return OFDM_OK;
 }
 int ofdm_hamming74_decode(ofdm_ctx *c, const uint8_t *in, int64_t n_bytes, uint8_t *out, uint32_t *corrected) {
     if (!c || n_bytes < 0 || (n_bytes >= 7 && (!in || !out))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     HIP_TRY(c, run_ham_decode(in, n_bytes, out, corrected, c->stream));
     return OFDM_OK;
 }
 
 // Schmidl-Cox parameters of a batch; false when no lag fits the capture (nothing can synchronise)
-static bool sc_make_params(const ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+static bool sc_make_params(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
                            int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric, ScParams &p) {
     const int L = c->S(), W = c->prm.sync_window_reps * L;
     const int64_t valid = frame_len - W - L + 1;
@@ -553,6 +620,7 @@ static bool sc_make_params(const ofdm_ctx *c, const float2 *in, int64_t n_frames
     p.L = L; p.W = W; p.threshold = (double)c->prm.sync_threshold;
     p.d_hat = d_hat; p.f_delta = f_delta; p.metric = metric;
     p.tiles_per_frame = 1; p.mode = 0;
+    p.tune = &c->tune; p.trace = &c->trace;
     return true;
 }
 
@@ -577,7 +645,7 @@ static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame
     // long periods (N >= 128): one streaming pass for chunk sums, then an exact search only where the chunk bounds allow a
     // crossing / a new maximum (kernels_scbig.hip); LDS footprint independent of L, so N = 4096 works too
     const bool one_small_tile = n_lags <= sc_tile_lags() && sc_lds_bytes(p) <= 64 * 1024; // bounded search, window in LDS: k_sc_tile reads less
-    if (sc_big_ok(p) && !one_small_tile && getenv("OFDM_NO_SC_BIG") == nullptr) {
+    if (sc_big_ok(p) && !one_small_tile && !c->tune.no_sc_big) {
         void *wsp;
         int rc = ws_get(c, 6, sc_big_workspace_bytes(p), &wsp);
         if (rc) return rc;
@@ -612,6 +680,7 @@ int ofdm_sc_correlate_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, 
     if (n_frames > 1 && frame_stride <= 0) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     return sc_run(c, reinterpret_cast<const float2 *>(in), n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric);
 }
 int ofdm_xcorr_batch(ofdm_ctx *c, const ofdm_fc32 *a, int64_t n_frames, int64_t a_stride, int64_t a_len, const ofdm_fc32 *b,
@@ -622,6 +691,7 @@ int ofdm_xcorr_batch(ofdm_ctx *c, const ofdm_fc32 *a, int64_t n_frames, int64_t 
     if (out && out_stride < 2 * a_len - 1) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     void *w;
     int rc = ws_get(c, 6, xcorr_workspace_bytes(n_frames, a_len, nb), &w);
     if (rc) return rc;
@@ -634,6 +704,7 @@ int ofdm_frequency_correction_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_
                                     int64_t right_offset, double *f_delta) {
     if (!c || n_pairs < 0 || (n_pairs && (!in || !f_delta))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     HIP_TRY(c, run_freq_correction(reinterpret_cast<const float2 *>(in), n_pairs, stride, right_offset, c->S(), f_delta, c->stream));
     return OFDM_OK;
 }
@@ -641,6 +712,7 @@ int ofdm_cfo_rotate_batch(ofdm_ctx *c, ofdm_fc32 *x, int64_t n_frames, int64_t f
                           const double *f_delta, const int32_t *first_index) {
     if (!c || n_frames < 0 || frame_len < 0 || (n_frames && (!x || !f_delta))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     HIP_TRY(c, run_cfo_rotate(reinterpret_cast<float2 *>(x), n_frames, frame_stride, frame_len, f_delta, first_index, c->stream));
     return OFDM_OK;
 }
@@ -648,6 +720,7 @@ int ofdm_estimate_channel_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_fram
                                 int64_t frame_len, const int32_t *offset, const double *f_delta, ofdm_fc32 *hk) {
     if (!c || n_frames < 0 || frame_len <= 0 || (n_frames && (!in || !hk))) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     SymParams p = base_params(c);
     p.in = reinterpret_cast<const float2 *>(in); p.out = reinterpret_cast<float2 *>(hk);
     p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
@@ -666,19 +739,17 @@ static int demod_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t fr
     p.offset = offset; p.f_delta = f_delta; p.nsym_frame = nsym_frame;
     p.hk = hk; p.hk_stride = hk_stride; p.out_bytes = out; p.out_stride = out_stride; p.soft = soft;
     if (c->prm.n_fft == 64) { // regular, aligned streams take the wave-centric fast path (kernels_fast.hip)
-        hipError_t e = run_demod64_fast(p, c->stream, c->num_cu);
+        hipError_t e = c->tune.no_fast64 ? hipErrorNotSupported : run_demod64_fast(p, c->stream, c->num_cu);
         if (e == hipSuccess) return OFDM_OK;
         if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
     if (c->prm.n_fft == 4096) { // 64 x 64 two-stage kernel for regular streams (kernels_fast.hip)
-        static const bool off = getenv("OFDM_NO_DEMOD4096") != nullptr; // A/B switch
-        hipError_t e = off ? hipErrorNotSupported : run_demod4096(p, c->stream, c->num_cu);
+        hipError_t e = c->tune.no_demod4096 ? hipErrorNotSupported : run_demod4096(p, c->stream, c->num_cu); // A/B switch
         if (e == hipSuccess) return OFDM_OK;
         if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
     if (c->prm.n_fft > 64 && c->prm.n_fft < 4096) { // R x 64 two-stage kernels for regular streams (kernels_mid.hip)
-        static const bool off = getenv("OFDM_NO_MID_KERNELS") != nullptr; // A/B switch
-        hipError_t e = off ? hipErrorNotSupported : run_demod_mid(c->prm.n_fft, p, c->stream, c->num_cu);
+        hipError_t e = c->tune.no_mid_kernels ? hipErrorNotSupported : run_demod_mid(c->prm.n_fft, p, c->stream, c->num_cu); // A/B switch
         if (e == hipSuccess) return OFDM_OK;
         if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
@@ -695,6 +766,7 @@ int ofdm_rx_demod_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int6
     if (hk && hk_stride != 0 && hk_stride != c->prm.n_fft) return OFDM_ERR_INVALID;
     if (!n_frames || !syms_per_frame) return OFDM_OK;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     return demod_run(c, reinterpret_cast<const float2 *>(in), n_frames, frame_stride, frame_len, first_symbol,
                      syms_per_frame, offset, f_delta, nullptr, reinterpret_cast<const float2 *>(hk), hk_stride, out,
                      out_stride, reinterpret_cast<float2 *>(soft));
@@ -709,6 +781,7 @@ int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, 
     if (out_stride < frame) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     const int S = c->S();
     const uint8_t *src = payload; int64_t src_stride = payload_stride; const int32_t *src_len = payload_len;
     int32_t src_bytes = payload_bytes;
@@ -729,19 +802,17 @@ int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, 
     p.payload = src; p.payload_stride = src_stride; p.payload_len = src_len; p.payload_bytes = src_bytes;
     p.out = reinterpret_cast<float2 *>(out); p.out_stride_s = out_stride;
     if (c->prm.n_fft == 64) { // one workgroup per frame, frame built in LDS, single pass over HBM
-        hipError_t fe = run_txframe64(p, c->d_header, c->header_max, c->stream, c->num_cu);
+        hipError_t fe = c->tune.no_txframe64 ? hipErrorNotSupported : run_txframe64(p, c->d_header, c->header_max, c->stream, c->num_cu);
         if (fe == hipSuccess) return OFDM_OK;
         if (fe != hipErrorNotSupported) { c->last_hip = (int)fe; return OFDM_ERR_HIP; }
     }
     if (c->prm.n_fft < 4096) { // R x 64 two-stage kernel, frames built twice: one pass over HBM (kernels_mid.hip)
-        static const bool off = getenv("OFDM_NO_MID_KERNELS") != nullptr;
-        hipError_t fe = off ? hipErrorNotSupported : run_txframe_mid(c->prm.n_fft, p, c->d_header, c->header_max, c->stream, c->num_cu);
+        hipError_t fe = c->tune.no_mid_kernels ? hipErrorNotSupported : run_txframe_mid(c->prm.n_fft, p, c->d_header, c->header_max, c->stream, c->num_cu);
         if (fe == hipSuccess) return OFDM_OK;
         if (fe != hipErrorNotSupported) { c->last_hip = (int)fe; return OFDM_ERR_HIP; }
     }
     if (c->prm.n_fft == 4096) { // 64 x 64 two-stage kernel, frames built twice: one pass over HBM (kernels_fast.hip)
-        static const bool off = getenv("OFDM_NO_DEMOD4096") != nullptr;
-        hipError_t fe = off ? hipErrorNotSupported : run_txframe4096(p, c->d_header, c->header_max, c->stream, c->num_cu);
+        hipError_t fe = c->tune.no_demod4096 ? hipErrorNotSupported : run_txframe4096(p, c->d_header, c->header_max, c->stream, c->num_cu);
         if (fe == hipSuccess) return OFDM_OK;
         if (fe != hipErrorNotSupported) { c->last_hip = (int)fe; return OFDM_ERR_HIP; }
     }
@@ -751,6 +822,7 @@ int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, 
     HIP_TRY(c, hipMemsetAsync(mx, 0, sizeof(unsigned) * (size_t)n_frames, c->stream));
     p.frame_max = (unsigned *)mx;
     HIP_TRY(c, run_tx_symbols(c->prm.n_fft, p, c->stream, c->num_cu));
+    c->trace.add("k_tx_finish");
     HIP_TRY(c, run_tx_finish(reinterpret_cast<float2 *>(out), n_frames, out_stride, 10 * S, frame, c->d_header,
                              c->header_max, (const unsigned *)mx, c->stream));
     return OFDM_OK;
@@ -770,6 +842,7 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     if (out_stride < (c->prm.ecc == OFDM_ECC_NONE ? body_max : (body_max / 7) * 4)) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     const int N = c->prm.n_fft;
     void *w_dhat, *w_fd, *w_off, *w_nsym, *w_hk = nullptr, *w_raw = nullptr;
     int rc;
@@ -784,10 +857,9 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     //    pass over HBM (k_sc_cf<..., BPS>, kernels_sync.hip).  The few frames its f32 filter cannot settle come back on
     //    a device-side list and take the list-mode kernels below.
     if (N == 64 && c->prm.sync_mode == OFDM_SYNC_SCHMIDL_COX) {
-        // Opt-in (OFDM_ONE_PASS_RX=1, read per call: the parity tests flip it): measured on MI355X the one-pass kernel moves
-        // half the HBM bytes of the staged chain but is VALU-issue bound with 12 wavefronts per CU (its LDS footprint), 2.2 ms
-        // against 1.95 ms per 262 144 config-3 frames; see DESIGN.md section 5.2.
-        const bool off = getenv("OFDM_ONE_PASS_RX") == nullptr;
+        // ofdm_params.rx_path = OFDM_RX_ONE_PASS (or ofdm_set_tuning "one_pass_rx"): the one-pass kernel moves half the HBM bytes
+        // of the staged chain but is VALU-issue bound with 12 wavefronts per CU (its LDS footprint); see DESIGN.md section 5.2.
+        const bool off = !c->tune.one_pass_rx;
         ScParams scp;
         ScRxFused rx;
         rx.bps = c->prm.modulation; rx.guard = c->prm.guard_bands; rx.backoff = c->prm.sync_backoff; rx.cfo_mode = c->prm.cfo_mode;
@@ -802,6 +874,7 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
             const int32_t *slow_list = nullptr, *slow_count = nullptr;
             HIP_TRY(c, run_sc_fast(scp, wsp, c->num_cu, c->stream, &rx, &slow_list, &slow_count));
             // slow-list frames (k_sc_tile has just redone their timing in f64): prepare -> receive body -> finish
+            c->trace.add("k_rx_prepare<list>");
             HIP_TRY(c, run_rx_prepare(n_frames, (const int32_t *)w_dhat, fd, frame_len, c->S(), c->prm.sync_backoff, c->prm.cfo_mode,
                                       max_symbols, bps_bytes, status, offs, (int32_t *)w_nsym, c->stream, slow_list, slow_count));
             SymParams p = base_params(c);
@@ -811,9 +884,11 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
             p.out_bytes = fin ? out : (uint8_t *)w_raw; p.out_stride = fin ? out_stride : raw_stride;
             HIP_TRY(c, fin ? run_rxframe64(p, nullptr, c->stream, c->num_cu, out, out_stride, out_len, slow_list, slow_count)
                            : run_rxframe64(p, nullptr, c->stream, c->num_cu, nullptr, 0, nullptr, slow_list, slow_count));
-            if (!fin)
+            if (!fin) {
+                c->trace.add("k_rx_finish<list>");
                 HIP_TRY(c, run_rx_finish((const uint8_t *)w_raw, raw_stride, n_frames, status, (const int32_t *)w_nsym, bps_bytes,
                                          c->prm.ecc, out, out_stride, out_len, c->stream, slow_list, slow_count));
+            }
             return OFDM_OK;
         }
     }
@@ -824,17 +899,23 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         if (frame_len > 0x3fffffff) return OFDM_ERR_UNSUPPORTED;
         void *w_x;
         if ((rc = ws_get(c, 6, xcorr_workspace_bytes(n_frames, frame_len, c->S()), &w_x))) return rc;
+        c->trace.add("k_xcorr+k_rx_prepare_ref");
         HIP_TRY(c, run_xcorr(x, n_frames, frame_stride, frame_len, c->d_header, c->S(), w_x, (int32_t *)w_dhat, metric, nullptr, 0,
                              c->num_cu, c->stream));
-        HIP_TRY(c, run_rx_prepare_ref(n_frames, (const int32_t *)w_dhat, frame_len, c->S(), max_symbols, bps_bytes, status, offs,
-                                      (int32_t *)w_nsym, c->stream));
+        // The REPORTED offset may be negative (idx_max - N, quirk Q1; -N for an all-zero capture) and goes to the caller's array
+        // only; the kernels below read the workspace copy, which is 0 for every frame whose status is not OFDM_FRAME_OK, so that
+        // no fetch can start in front of the capture.
+        HIP_TRY(c, run_rx_prepare_ref(n_frames, (const int32_t *)w_dhat, frame_len, c->S(), max_symbols, bps_bytes, status, offset,
+                                      (int32_t *)w_off, (int32_t *)w_nsym, c->stream));
+        offs = (int32_t *)w_off;
         if (c->prm.cfo_mode == OFDM_CFO_OFF) HIP_TRY(c, hipMemsetAsync(fd, 0, sizeof(double) * (size_t)n_frames, c->stream));
-        else HIP_TRY(c, run_freq_correction(x + 3 * c->S(), n_frames, frame_stride, c->S(), c->S(), fd, c->stream, offs, status));
+        else { c->trace.add("k_freq_corr"); HIP_TRY(c, run_freq_correction(x + 3 * c->S(), n_frames, frame_stride, c->S(), c->S(), fd, c->stream, offs, status)); }
     } else {
     // 1. timing + CFO: Schmidl-Cox over the repeated preamble (replaces xcorr_fft, src/receiver.rs:20-25,39)
     rc = sc_run(c, x, n_frames, frame_stride, frame_len, n_lags, (int32_t *)w_dhat, fd, metric);
     if (rc) return rc;
     // 2. trimmed start, length check, live symbols (receiver.rs:21-36)
+    c->trace.add("k_rx_prepare");
     HIP_TRY(c, run_rx_prepare(n_frames, (const int32_t *)w_dhat, fd, frame_len, c->S(), c->prm.sync_backoff,
                               c->prm.cfo_mode, max_symbols, bps_bytes, status, offs, (int32_t *)w_nsym, c->stream));
     }
@@ -842,7 +923,7 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     //      demap (receiver.rs:44-83).  N = 64: one fused wave-centric kernel; otherwise the generic pair.
     bool fused = false, finished = false;
     if (N == 1024) { // one workgroup per frame: channel estimate kept in registers, 16 x 64 FFT (kernels_fast.hip)
-        static const bool off = getenv("OFDM_NO_RXFRAME1024") != nullptr; // A/B switch
+        const bool off = c->tune.no_rxframe1024 != 0; // A/B switch
         SymParams p = base_params(c);
         p.in = x; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
         p.offset = offs; p.f_delta = fd; p.nsym_frame = (const int32_t *)w_nsym;
@@ -874,9 +955,11 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         if (rc) return rc;
     }
     // 5. length header, truncate [, Hamming decode] (receiver.rs:85-95)
-    if (!finished)
+    if (!finished) {
+        c->trace.add("k_rx_finish");
         HIP_TRY(c, run_rx_finish((const uint8_t *)w_raw, raw_stride, n_frames, status, (const int32_t *)w_nsym, bps_bytes,
                                  c->prm.ecc, out, out_stride, out_len, c->stream));
+    }
     return OFDM_OK;
 }
 
@@ -900,6 +983,7 @@ int ofdm_channel_batch(ofdm_ctx *c, const ofdm_fc32 *tx, int64_t n_frames, int64
     if (!(snr_db == snr_db)) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     ChannelParams p;
     p.tx = reinterpret_cast<const float2 *>(tx); p.n_frames = n_frames; p.tx_stride = tx_stride; p.tx_len = tx_len;
     p.snr_lin = std::pow(10.0, snr_db / 10.0); // channel.rs:40
@@ -914,6 +998,7 @@ int ofdm_channel_batch(ofdm_ctx *c, const ofdm_fc32 *tx, int64_t n_frames, int64
 int ofdm_hbm_read_probe(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_symbols, int32_t pattern) {
     if (!c || n_symbols < 0 || pattern < 0 || pattern > 2 || (n_symbols && !in)) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    c->trace.reset();
     void *sink;
     int rc = ws_get(c, 7, 64, &sink);
     if (rc) return rc;

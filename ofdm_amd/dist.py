@@ -17,6 +17,43 @@ def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     return (n_frames * rank) // world, (n_frames * (rank + 1)) // world
 
 
+def halo_ranges(n_samples: int, rank: int, world: int, L: int, W: int) -> Tuple[int, int, int, int, int]:
+    """Continuous-capture variant of the split (the reference's caller is examples/jetson_rx.rs:16,48-49,86: one
+    decode! per 2 M-sample buffer): the Schmidl-Cox search of ONE long capture over `world` ranks with no exchange.
+
+    The capture has `n_samples - W - L + 1` lags.  Rank r owns the contiguous lag range [lag_lo, lag_hi) and reads the samples
+    [lag_lo, sample_hi): its own lags, plus W more lags because the detector is threshold-then-peak -- a first crossing at the
+    last own lag is followed by a peak window of W lags -- plus the W + L - 1 samples the last of those
+    windows spans.  The overlap of 2 W + L - 1 samples is a read-only halo (overhead, not algorithmic bytes).
+
+    Returns (lag_lo, lag_hi, sample_lo, sample_hi, n_lags): run sc_correlate on samples [sample_lo, sample_hi) with that n_lags;
+    a detection d_hat >= 0 there is the capture's lag lag_lo + d_hat.  merge_first_detection() combines the ranks' answers into
+    exactly what one search over the whole capture returns."""
+    if world <= 0 or not (0 <= rank < world) or L <= 0 or W <= 0:
+        raise ValueError("bad halo request")
+    valid = n_samples - W - L + 1
+    if valid <= 0:
+        return 0, 0, 0, max(n_samples, 0), 0
+    lag_lo, lag_hi = shard_range(valid, rank, world)
+    n_lags = min(lag_hi - lag_lo + W, valid - lag_lo)  # the peak window may run W lags past the own range, never past the capture
+    if lag_hi == lag_lo:
+        n_lags = 0
+    sample_hi = min(n_samples, lag_lo + n_lags + W + L - 1)
+    return lag_lo, lag_hi, lag_lo, sample_hi, n_lags
+
+
+def merge_first_detection(detections):
+    """detections: per rank, in rank order, (lag_lo, lag_hi, d_hat, f_delta, metric) with d_hat relative to lag_lo (-1 = none).
+    The capture's detection is the one of the LOWEST rank that has any: its first crossing is the capture's first crossing
+    (lower ranks saw none in their own ranges, and a crossing it found in its W-lag overrun is the next rank's first crossing
+    with the same peak window, hence the same answer).  Returns (d_hat, f_delta, metric) with d_hat a lag of the whole capture,
+    or (-1, 0.0, 0.0)."""
+    for lag_lo, lag_hi, d_hat, f_delta, metric in detections:
+        if d_hat is not None and d_hat >= 0:
+            return lag_lo + int(d_hat), float(f_delta), float(metric)
+    return -1, 0.0, 0.0
+
+
 def env_world() -> Tuple[int, int, int]:
     """(world_size, rank, local_rank) from the torchrun environment (1, 0, 0 when launched plainly)."""
     return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),

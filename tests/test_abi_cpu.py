@@ -48,6 +48,21 @@ def test_no_oracle_or_torch_in_the_boundary(lib):
                 assert "import oracle" not in src and "from oracle" not in src and "ofdm_oracle" not in src, f
 
 
+def test_library_reads_no_environment_variable(lib):
+    """Tuning and A/B switches are per-context state set through ofdm_set_tuning (include/ofdm_hip.h); nothing under
+    ofdm_amd/csrc may consult the environment, and the profiling branches must sit behind the profile build's constant."""
+    for root, _, files in os.walk(os.path.join(ROOT, "ofdm_amd", "csrc")):
+        for f in files:
+            if f.endswith((".hip", ".hpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "getenv" not in src, f
+    lib.ofdm_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.ofdm_last_dispatch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    assert lib.ofdm_set_tuning(None, b"grid_cap", 1) == -1          # no context: invalid, never a crash
+    buf = C.create_string_buffer(8)
+    assert lib.ofdm_last_dispatch(None, buf, 8) == -1
+
+
 def test_host_entry_points(lib, orc):
     from ofdm_amd import Params
 

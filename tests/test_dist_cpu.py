@@ -26,6 +26,103 @@ def test_shard_range_partitions_exactly():
         shard_range(10, 2, 2)
 
 
+def test_halo_split_of_a_long_capture_equals_the_whole_search(orc):
+    """SURVEY.md 8(e), continuous-stream variant (the reference's caller: examples/jetson_rx.rs:16,48-49,86, one decode! per
+    long buffer): the Schmidl-Cox search of ONE capture split over `world` ranks by lag range with a read-only halo of
+    2 W + L - 1 samples and no exchange.  Per shard the worker is the oracle's sc_sync on the shard's samples with the shard's
+    n_lags; the merged detection must be exactly the whole capture's -- for a two-frame capture, a frame that straddles a shard
+    boundary, a crossing in the last lags of a shard (peak in the next one's range), and a noise-only capture."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ofdm_amd.dist import halo_ranges, merge_first_detection
+    from util import through_channel
+
+    L, reps = 80, 3
+    W = reps * L
+    rng = np.random.default_rng(2026)
+    tx = [orc.encode(bytes(rng.integers(0, 256, 300, dtype=np.uint8)), True, orc.QAM64, 64) for _ in range(2)]
+    flen = tx[0].size
+    n = 9000
+    for case, starts in (("two frames", (700, 5200)), ("second half only", (4600,)), ("straddles the cut", (4300 - 120,)),
+                         ("late", (n - flen - 30,)), ("noise only", ())):
+        cap = np.zeros(n, np.complex128)
+        for t, st in zip(tx, starts):
+            cap += through_channel(orc, rng, t, n, st, 0.004, snr_db=None, data_start=800).astype(np.complex128)
+        cap += 0.004 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        cap = cap.astype(np.complex64).astype(np.complex128)
+        want_d, _, want_m, want_fd = orc.sc_sync(cap, L=L, window_reps=reps, n_lags=0, threshold=0.5)
+        assert (want_d >= 0) == bool(starts), case
+        for world in (1, 2, 3, 4, 7):
+            dets, covered = [], 0
+            for r in range(world):
+                lag_lo, lag_hi, s_lo, s_hi, n_lags = halo_ranges(n, r, world, L, W)
+                assert lag_lo == covered and s_lo == lag_lo and s_hi <= n
+                covered = lag_hi
+                assert s_hi - s_lo <= (lag_hi - lag_lo) + 2 * W + L - 1          # own lags + the halo, never more
+                if n_lags == 0:
+                    dets.append((lag_lo, lag_hi, -1, 0.0, 0.0))
+                    continue
+                d, _, m, fd = orc.sc_sync(cap[s_lo:s_hi], L=L, window_reps=reps, n_lags=n_lags, threshold=0.5)
+                dets.append((lag_lo, lag_hi, d, fd, m))
+            assert covered == n - W - L + 1
+            got_d, got_fd, got_m = merge_first_detection(dets)
+            assert got_d == want_d, (case, world, got_d, want_d)
+            if want_d >= 0:
+                assert abs(got_fd - want_fd) <= 1e-12 and abs(got_m - want_m) <= 1e-12, (case, world)
+    assert halo_ranges(100, 0, 2, 80, 240) == (0, 0, 0, 100, 0)                   # no lag fits: nothing to search
+    with pytest.raises(ValueError):
+        halo_ranges(1000, 2, 2, 80, 240)
+
+
+class _FakeCtx:
+    """Stands in for api.Context in the timing helper: the 'kernel' is a sleep, the 'event timer' the wall clock."""
+
+    def timer_start(self):
+        import time
+        self.t0 = time.perf_counter()
+
+    def timer_stop_ms(self):
+        import time
+        return (time.perf_counter() - self.t0) * 1e3
+
+
+class _FakeTorch:
+    class cuda:
+        @staticmethod
+        def synchronize():
+            pass
+
+
+def _timing_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import time
+    from ofdm_amd.dist import Group
+    from tools import rank_timing
+
+    g = Group(backend="gloo")
+    ms, per_rank, r = rank_timing.timed(_FakeCtx(), _FakeTorch, lambda: time.sleep(0.01 * (rank + 1)) or rank, 3, g)
+    if rank == 0:
+        q.put((ms, per_rank, r))
+    g.close()
+
+
+def test_config_block_timing_is_max_over_ranks():
+    """tools/rank_timing.timed -- the timed region of bench.py's config 3 / 4 / 5 blocks under --gpus N: every rank times its
+    own K launches between barriers, the job's step time is the slowest rank's, every rank's own time is reported."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_timing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ms, per_rank, r = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len(per_rank) == 2 and ms == max(per_rank) and per_rank[1] > per_rank[0] and per_rank[0] >= 9.0 and r == 0
+
+
 def _worker(rank, world, port, q):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -88,6 +185,11 @@ def test_bench_gpus_n_starts_n_ranks():
     rec = recs[0]
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["world_size_seen"] == 2
     assert len(rec["ms_per_step_per_rank"]) == 2 and rec["ms_per_step"] >= max(rec["ms_per_step_per_rank"]) - 1e-9
+    # configs 3, 4 and 5 run on every rank too (BASELINE configs[3] / [4] are 8-GPU workloads): their blocks carry n_gpus: 2,
+    # per-rank times, and config 4's stream is frame-sharded over the ranks with nothing lost
+    for name in ("cfg3", "cfg4", "cfg5"):
+        assert rec[name]["n_gpus"] == 2 and len(rec[name]["ms_per_rank"]) == 2 and rec[name]["ms"] == max(rec[name]["ms_per_rank"])
+    assert rec["cfg4"]["stream_frames_all_ranks"] == rec["cfg4"]["stream_frames"] == 10_000_000
 
 
 def test_bench_gpus_1_is_single_rank():

@@ -179,10 +179,14 @@ def test_rx_demod_fast64_every_instantiation(api, orc, mod, guard, hk_on):
     hkd = None if hk is None else dev(ctx, hk)
     for k in (8, 16, 24):
         out = ctx.rx_demod(xd.reshape(nsym // k, k * 80), syms_per_frame=k, hk=hkd)   # no soft -> k_demod64
+        # the kernel that ran, not only the bytes: the launcher falls back to the generic k_sym outside its envelope
+        want_kernel = "k_demod64<burst%d>" % (16 if nsym // 8 % 16 == 0 else 8 if nsym // 8 % 8 == 0 else 4) if (mod, guard, hk_on) == (6, True, False) else "k_demod64"
+        assert ctx.last_dispatch() == want_kernel, (ctx.last_dispatch(), k)
         excused = assert_bytes_match(bytes(host(out).ravel()), want, wsoft, mod, what=f"k_demod64<{mod},{guard},{hk_on}> k={k}")
         assert excused <= 2
     # first_symbol > 0 and a frame stride larger than the frame: symbols 8..15 of 24-symbol frames
     out = ctx.rx_demod(xd.reshape(frames24, 24 * 80), syms_per_frame=8, first_symbol=8, hk=hkd)
+    assert ctx.last_dispatch().startswith("k_demod64")
     bps = ctx.bytes_per_symbol
     wsel = np.frombuffer(want, np.uint8).reshape(frames24, 24 * bps)[:, 8 * bps:16 * bps]
     ssel = np.asarray(wsoft).reshape(frames24, 24, -1)[:, 8:16].reshape(-1)
@@ -202,12 +206,14 @@ def test_rx_demod_4096_many_symbols_per_frame(api, orc, mod, guard, per_frame_hk
     hks = fc32(1.0 + 0.2 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n))))
     if mod == 2:
         out = host(ctx.rx_demod(dev(ctx, xs), k))
+        assert ctx.last_dispatch() == "k_demod4096"
         want, wsoft = orc.rx_demod(wide(x), n, guard, mod, want_soft=True)
         assert want == data
         assert_bytes_match(bytes(out.ravel()), want, wsoft, mod, what="k_demod4096 H=1")
         return
     hk_dev = dev(ctx, hks if per_frame_hk else hks[0])
     out = host(ctx.rx_demod(dev(ctx, xs), k, hk=hk_dev))
+    assert ctx.last_dispatch() == "k_demod4096"
     for f in range(nf):
         want, wsoft = orc.rx_demod(wide(xs[f]), n, guard, mod, hk=wide(hks[f if per_frame_hk else 0]), want_soft=True)
         assert_bytes_match(bytes(out[f]), want, wsoft, mod, what=f"k_demod4096 frame {f}")
@@ -215,31 +221,34 @@ def test_rx_demod_4096_many_symbols_per_frame(api, orc, mod, guard, per_frame_hk
 
 @pytest.mark.parametrize("guard", [True, False])
 @pytest.mark.parametrize("n", [128, 256, 512, 1024, 2048])
-def test_rx_demod_mid_every_instantiation(api, orc, n, guard, monkeypatch):
+def test_rx_demod_mid_every_instantiation(api, orc, n, guard):
     """k_demod_mid<R, BPS, GUARD> (kernels_mid.hip, N = 64 R) against the oracle for every modulation, 11 symbols per frame
     (frame boundaries fall inside a workgroup step), no / shared / per-frame channel, on a 3-workgroup grid so that every
-    workgroup runs several steps of the prefetch and deferred-store pipeline.  src/receiver.rs:99-190."""
-    monkeypatch.setenv("OFDM_MID_GRID", "3")
+    workgroup runs several steps of the prefetch and deferred-store pipeline; every call asserts that k_demod_mid served it
+    (ofdm_last_dispatch), not the generic fallback.  src/receiver.rs:99-190."""
     k = 11
     nf = max(3, -(-7 * (32 // (n // 64)) // k))
     S = n + n // 4
     for mod in (1, 2, 4, 6, 8):
         rng = np.random.default_rng(n * 10 + mod)
         x, data = make_symbols_np(orc, rng, k * nf, n, guard, mod, snr_db=38.0)
-        ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+        ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard, tuning={"grid_cap": 3})
         xs = x.reshape(nf, k * S)
         out = host(ctx.rx_demod(dev(ctx, xs), k))
+        assert ctx.last_dispatch() == "k_demod_mid"
         want, wsoft = orc.rx_demod(wide(x), n, guard, mod, want_soft=True)
         assert want == data
         assert_bytes_match(bytes(out.ravel()), want, wsoft, mod, what=f"k_demod_mid<{n // 64},{mod},{guard}> H=1")
         hks = fc32(1.0 + 0.2 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n))))
         for per_frame in (False, True):
             out = host(ctx.rx_demod(dev(ctx, xs), k, hk=dev(ctx, hks if per_frame else hks[0])))
+            assert ctx.last_dispatch() == "k_demod_mid"
             for f in (0, nf // 2, nf - 1):
                 want, wsoft = orc.rx_demod(wide(xs[f]), n, guard, mod, hk=wide(hks[f if per_frame else 0]), want_soft=True)
                 assert_bytes_match(bytes(out[f]), want, wsoft, mod, what=f"k_demod_mid<{n // 64},{mod},{guard}> frame {f}")
         # first_symbol > 0 on a stride larger than the part demodulated
         out = host(ctx.rx_demod(dev(ctx, xs), 4, first_symbol=5))
+        assert ctx.last_dispatch() == "k_demod_mid"
         want, wsoft = orc.rx_demod(wide(x), n, guard, mod, want_soft=True)
         bps = ctx.bytes_per_symbol
         wsel = np.frombuffer(want, np.uint8).reshape(nf, k * bps)[:, 5 * bps:9 * bps]
@@ -248,22 +257,22 @@ def test_rx_demod_mid_every_instantiation(api, orc, n, guard, monkeypatch):
 
 
 @pytest.mark.parametrize("guard", [True, False])
-@pytest.mark.parametrize("n", [64, 128, 256, 512, 1024, 2048])
-def test_tx_symbols_mid_every_instantiation(api, orc, n, guard, monkeypatch):
-    """k_tx_mid<R, GUARD> (kernels_mid.hip) against the oracle's modulate + encode_block + prefix_block for every
-    modulation: a stream that ends inside a symbol, pilot-only symbols behind it, several steps per workgroup.
-    src/transmitter.rs:40-53, 108-181."""
+@pytest.mark.parametrize("n", [64, 128, 256, 512, 1024, 2048, 4096])
+def test_tx_symbols_mid_every_instantiation(api, orc, n, guard):
+    """k_tx_mid<R, GUARD> (kernels_mid.hip) and k_tx4096<GUARD> (kernels_fast.hip) against the oracle's modulate + encode_block +
+    prefix_block for every modulation: a stream that ends inside a symbol, pilot-only symbols behind it, a 2-workgroup grid
+    (>= 4 steps of the byte-prefetch pipeline per workgroup).  src/transmitter.rs:40-53, 108-181."""
     import torch
-    monkeypatch.setenv("OFDM_MID_GRID", "2")
-    G = 32 // (n // 64)
+    G = max(1, 32 // (n // 64))
     n_sym = 5 * G + 3
     for mod in (1, 2, 4, 6, 8):
         rng = np.random.default_rng(n * 7 + mod)
-        ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+        ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard, tuning={"grid_cap": 2})
         bps, nd = ctx.bytes_per_symbol, ctx.data_carriers
         nb = (n_sym - 3) * bps + bps // 3 + 1          # the last byte-carrying symbol is partly filled, two carry only pilots
         data = rng.integers(0, 256, nb, dtype=np.uint8)
         fused = host(ctx.tx_symbols(torch.from_numpy(data.copy()).to(ctx.device), n_sym=n_sym))
+        assert ctx.last_dispatch() == ("k_tx4096" if n == 4096 else "k_tx_mid")
         opts = np.asarray(orc.modulate(bytes(data), mod))
         pts = np.zeros(n_sym * nd, np.complex128)
         pts[: opts.size] = opts
@@ -276,15 +285,14 @@ def test_tx_symbols_mid_every_instantiation(api, orc, n, guard, monkeypatch):
 
 @pytest.mark.parametrize("n,mod,guard", [(128, 6, True), (256, 2, False), (512, 8, True), (1024, 4, True), (2048, 6, False),
                                          (4096, 8, True), (4096, 6, False)])
-def test_rx_demod_mid_frame_mode(api, orc, n, mod, guard, monkeypatch):
+def test_rx_demod_mid_frame_mode(api, orc, n, mod, guard):
     """k_demod_mid<..., FRAME = true> / k_demod4096<..., FRAME = true>: what the decode chain asks of the demodulator after timing (src/receiver.rs:20-83) --
     a per-frame start offset, CFO derotation with sample ids counted from that start, a per-frame channel, and zero-fill past
     the end of the capture (pad_chunk, receiver.rs:203-210) -- against the oracle, frame by frame, on a 3-workgroup grid."""
     import torch
-    monkeypatch.setenv("OFDM_MID_GRID", "3")
     rng = np.random.default_rng(n + mod)
     S, k, nf = n + n // 4, 7, 6
-    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard, tuning={"grid_cap": 3})
     x, _ = make_symbols_np(orc, rng, k * nf, n, guard, mod, snr_db=38.0)
     x = wide(x).reshape(nf, k * S)
     offs = rng.integers(0, 97, nf).astype(np.int32)
@@ -298,6 +306,7 @@ def test_rx_demod_mid_frame_mode(api, orc, n, mod, guard, monkeypatch):
     cut = span - (S // 2 + 13)   # the capture ends inside the last symbol of the frames with the largest offsets
     out = host(ctx.rx_demod(dev(ctx, fc32(frames)), k, offset=torch.from_numpy(offs).to(ctx.device),
                             f_delta=torch.from_numpy(fds).to(ctx.device), hk=dev(ctx, hks), frame_len=cut))
+    assert ctx.last_dispatch() == ("k_demod4096<frame>" if n == 4096 else "k_demod_mid<frame>")
     for f in range(nf):
         seg = wide(fc32(frames[f]))[: cut][offs[f]:]
         seg = np.concatenate([seg, np.zeros(max(0, k * S - seg.size), np.complex128)])[: k * S]
@@ -555,20 +564,20 @@ def test_tx_encode_batch(api, orc, n, mod, guard, nbytes, ecc):
 @pytest.mark.parametrize("n,mod,guard,nbytes", [(64, 6, True, 2300), (64, 1, True, 400), (64, 2, False, 1000), (128, 6, True, 200), (128, 2, False, 3), (256, 4, True, 700), (512, 8, True, 2000),
                                                  (512, 1, False, 100), (1024, 6, False, 2500), (2048, 4, True, 4000), (4096, 8, True, 9000),
                                                  (4096, 2, False, 2500)])
-def test_tx_encode_mid_frames(api, orc, n, mod, guard, nbytes, monkeypatch):
+def test_tx_encode_mid_frames(api, orc, n, mod, guard, nbytes):
     """k_txframe_mid / k_txframe4096 (encode in one HBM pass for N = 128 .. 4096 and for N = 64 frames of more than 56 data
     symbols: every frame built twice, once for its maximum) against the oracle's encode, 11 frames with ragged payload lengths on a 2-workgroup grid (several rounds per workgroup, a last
     round that is only partly filled).  src/transmitter.rs:11-58, 184-188."""
     import torch
-    monkeypatch.setenv("OFDM_MID_GRID", "2")
     rng = np.random.default_rng(n + mod + nbytes)
-    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard, tuning={"grid_cap": 2})
     nfr = 11
     lens = rng.integers(0, nbytes + 1, nfr).astype(np.int32)
     lens[0], lens[-1] = nbytes, 0
     pay = rng.integers(0, 256, (nfr, nbytes), dtype=np.uint8)
     frames = host(ctx.encode_batch(torch.from_numpy(pay).to(ctx.device), lens=torch.from_numpy(lens)))
     S, D = n + n // 4, ctx.data_symbols(nbytes)
+    assert ctx.last_dispatch() == ("k_txframe4096" if n == 4096 else "k_txframe_mid" if n > 64 or D > 56 else "k_txframe64")
     assert frames.shape == (nfr, (10 + D) * S)
     for f in range(nfr):
         # up to its own last data symbol the frame equals the oracle's frame for that payload: the pilot-only symbols that
@@ -689,13 +698,13 @@ def test_rx_decode_truncated_and_limited(api, orc, n, mod, guard):
 def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod, guard, ecc, cfo_mode):
     """The one-pass receive kernel (k_sc_cf<..., BPS>: timing + CFO + channel estimate + demod + finish from the frame's
     LDS image) against (a) the staged chain (k_sc_cf + k_sc_post + k_rx_prepare + k_rxframe64 [+ k_rx_finish]; switched in
-    the default; the one-pass kernel is switched in with OFDM_ONE_PASS_RX=1) -- every output identical except the CFO (two f64 atan2 evaluations: <= 1e-13) and decisions
+    ofdm_params.rx_path = OFDM_RX_STAGED; the one-pass kernel is OFDM_RX_ONE_PASS) -- every output identical except the CFO (two f64 atan2 evaluations: <= 1e-13) and decisions
     the CFO's last bits can move -- and (b) the oracle, on a batch that mixes clean frames, noise-only slots (NOSYNC),
     captures cut inside the header (SHORT) or inside a data symbol (pad_chunk), and a limited symbol count.
     src/receiver.rs:9-96."""
-    import os
     rng = np.random.default_rng(900 + mod + ecc + cfo_mode)
-    ctx = api.Context(n_fft=64, modulation=mod, guard_bands=guard, ecc=ecc, cfo_mode=cfo_mode)
+    ctx = api.Context(n_fft=64, modulation=mod, guard_bands=guard, ecc=ecc, cfo_mode=cfo_mode, rx_path=api.RX_STAGED)
+    ctx1 = api.Context(n_fft=64, modulation=mod, guard_bands=guard, ecc=ecc, cfo_mode=cfo_mode, rx_path=api.RX_ONE_PASS)
     nbytes = 200 if mod > 1 else 100
     D = ctx.data_symbols(nbytes)
     flen = ctx.frame_samples(nbytes)
@@ -718,12 +727,11 @@ def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod,
     frame_lens = {"full": span, "cut_data": flen - 100, "cut_head": 700}
     for label, flen_used in frame_lens.items():
         for max_sym in (D, max(1, D - 3)):
-            os.environ["OFDM_ONE_PASS_RX"] = "1"
-            try:
-                one = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=max_sym, frame_len=flen_used).items()}
-            finally:
-                os.environ.pop("OFDM_ONE_PASS_RX", None)
+            one = {k: host(v) for k, v in ctx1.decode_batch(dev(ctx1, caps), max_symbols=max_sym, frame_len=flen_used).items()}
+            assert ctx1.last_dispatch().startswith("k_sc_cf<rx>+k_sc_tile<list>+k_rx_prepare<list>+k_rxframe64<list>"), ctx1.last_dispatch()
             two = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=max_sym, frame_len=flen_used).items()}
+            d2 = ctx.last_dispatch()
+            assert d2.startswith("k_sc_cf<") and "<rx>" not in d2 and "+k_rx_prepare+k_rxframe64" in d2, d2
             assert np.array_equal(one["status"], two["status"]) and np.array_equal(one["offset"], two["offset"])
             assert np.array_equal(one["len"], two["len"])
             assert np.allclose(one["f_delta"], two["f_delta"], rtol=0, atol=1e-13)
@@ -751,8 +759,8 @@ def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod,
 
 
 # ------------------------------------------------------------------ EXT-3 for long periods (kernels_scbig.hip), EXT-4 decode up to N = 4096
-def test_long_period_fine_tiles_agree(api, monkeypatch):
-    """k_scb_fine<5> (320-lag tiles, the default for N <= 2048) and k_scb_fine<10> (640-lag tiles, OFDM_SCB_BIG_TILES=1) walk the
+def test_long_period_fine_tiles_agree(api):
+    """k_scb_fine<5> (320-lag tiles, the default for N <= 2048) and k_scb_fine<10> (640-lag tiles, tuning "scb_big_tiles") walk the
     same exact sums in different tile sizes: identical timing index, CFO to 1e-12 and metric to 1e-6 on 96 N = 1024 captures from the library's
     TX and GPU channel (each tiling is compared with the oracle in test_sc_correlate_and_decode_long_periods)."""
     import math
@@ -766,8 +774,10 @@ def test_long_period_fine_tiles_agree(api, monkeypatch):
     fd = (torch.rand((nfr,), device=ctx.device, generator=g, dtype=torch.float64) * 1.8 - 0.9) * math.pi / ctx.S
     x = ctx.channel_batch(tx, snr_db=35.0, seed=9, delay=d, f_delta=fd, span=tx.shape[1] + 1536)
     small = [host(v) for v in ctx.sc_correlate(x)]
-    monkeypatch.setenv("OFDM_SCB_BIG_TILES", "1")
+    assert ctx.last_dispatch() == "k_scb_chunks<contig>+k_scb_fine<5>"
+    ctx.set_tuning("scb_big_tiles", 1)
     big = [host(v) for v in ctx.sc_correlate(x)]
+    assert ctx.last_dispatch() == "k_scb_chunks<contig>+k_scb_fine<10>"
     assert (small[0] >= 0).all() and np.array_equal(small[0], big[0])
     # the f64 sums are accumulated in a different order: equal to rounding, not to the bit
     assert np.abs(small[1] - big[1]).max() <= 1e-12 and np.abs(small[2] - big[2]).max() <= 1e-6
@@ -929,6 +939,178 @@ def test_rx_decode_reference_sync_mode(api, orc, n, mod, guard, nbytes):
             from util import decision_margin
             assert np.all(decision_margin(np.asarray(w["soft"])[pts], mod) < TOL), f
     assert n_ok >= 5 and res["status"][6] == -3 and res["offset"][6] == -1
+
+
+@pytest.mark.parametrize("n,mod,guard,nbytes", [(256, 4, True, 300), (4096, 6, True, 5000)])
+def test_rx_decode_reference_mode_negative_offsets_first(api, orc, n, mod, guard, nbytes):
+    """OFDM_SYNC_REFERENCE reports offset = idx_max - N (src/receiver.rs:21): -N for an all-zero capture (idx_max stays 0,
+    src/signals/mod.rs:206-207) and -1 for a zero-delay one (quirk Q1).  For the lengths whose chain is the generic channel
+    estimate + k_demod_mid / k_demod4096 (N outside {64, 1024}) that value used to reach fetches that only test an upper
+    bound.  Here those two captures come FIRST (a read in front of row 0 is a read in front of the allocation), on a
+    2-workgroup grid so that their dead symbols are followed by live ones in the same workgroup slot."""
+    rng = np.random.default_rng(21 + n + mod)
+    S = n + n // 4
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard, sync_mode=api.SYNC_REFERENCE, cfo_mode=api.CFO_ABS,
+                      tuning={"grid_cap": 2})
+    D = ctx.data_symbols(nbytes)
+    flen = ctx.frame_samples(nbytes)
+    span = flen + S
+    caps = [np.zeros(span, np.complex64)]                                # all-zero: idx_max 0 -> offset -span
+    tx = orc.encode(bytes(rng.integers(0, 256, nbytes, dtype=np.uint8)), guard, mod, n)
+    z = np.zeros(span, np.complex64); z[: tx.size] = fc32(tx)            # zero delay, no channel: lag 0 -> offset -1
+    caps.append(z)
+    for f in range(4):
+        tx = orc.encode(bytes(rng.integers(0, 256, nbytes, dtype=np.uint8)), guard, mod, n)
+        caps.append(through_channel(orc, rng, tx, span, int(rng.integers(2, S // 2)), rng.random() * 0.5 * np.pi / S, 34.0,
+                                    data_start=10 * S))
+    caps = np.stack(caps)
+    res = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=D + 2).items()}
+    disp = ctx.last_dispatch()
+    assert disp == "k_xcorr+k_rx_prepare_ref+k_freq_corr+k_sym<chest>+" + ("k_demod4096<frame>" if n == 4096 else "k_demod_mid<frame>") + "+k_rx_finish", disp
+    assert list(res["status"][:2]) == [-3, -3] and list(res["offset"][:2]) == [-span, -1] and list(res["len"][:2]) == [0, 0]
+    for f in range(caps.shape[0]):
+        w = orc.decode_ref(wide(caps[f]), guard, mod, n, want_soft=True)
+        assert res["status"][f] == w["status"] and res["offset"][f] == w["offset"], (f, res["status"][f], w["status"])
+        if w["status"] != 0:
+            continue
+        assert abs(res["f_delta"][f] - w["f_delta"]) <= 1e-9
+        got = bytes(res["bytes"][f][: res["len"][f]])
+        if got != w["bytes"]:
+            assert len(got) == len(w["bytes"])
+            gb = np.unpackbits(np.frombuffer(got, np.uint8), bitorder="little")
+            wb = np.unpackbits(np.frombuffer(w["bytes"], np.uint8), bitorder="little")
+            pts = np.unique((128 + np.nonzero(gb != wb)[0]) // mod)
+            from util import decision_margin
+            assert np.all(decision_margin(np.asarray(w["soft"])[pts], mod) < TOL), f
+    assert int((res["status"][2:] == 0).sum()) == 4
+
+
+@pytest.mark.parametrize("grid_cap", [1, 2, 3])
+@pytest.mark.parametrize("n,mod,nbytes", [(512, 2, 700), (4096, 6, 5000), (128, 4, 200), (2048, 8, 6000)])
+def test_rx_decode_dead_symbols_precede_live_ones(api, orc, n, mod, nbytes, grid_cap):
+    """A dead symbol -- one past a frame's live count (failed sync, short capture, max_symbols above the frame's own count) --
+    must leave the demodulator's packed LDS image untouched: nothing flushes or clears it after such a step, and demap(0)
+    is non-zero for every modulation above BPSK, so stale bits would be OR-ed into the next LIVE symbol of the same
+    (workgroup, slot) of the persistent loop (k_demod_mid<FRAME> / k_demod4096<FRAME>).  The no-sync and the short
+    frame come FIRST, max_symbols exceeds every frame's own count, and the grid is capped at 1 .. 3 workgroups so that the
+    dead steps are followed by live ones in the same slot.  Bytes, lengths, status against orc.decode_sc.  src/receiver.rs:64-95."""
+    rng = np.random.default_rng(555 + n + mod)
+    S = n + n // 4
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=True, tuning={"grid_cap": grid_cap})
+    D = ctx.data_symbols(nbytes)
+    flen = ctx.frame_samples(nbytes)
+    span = (flen + S // 2 + 80) // 2 * 2            # room for the delay, less than one more whole symbol
+    max_sym = D + 3
+    caps = [fc32(0.05 * (rng.standard_normal(span) + 1j * rng.standard_normal(span)))]          # noise only: NOSYNC, 0 live symbols
+    for f in range(6):
+        tx = orc.encode(bytes(rng.integers(0, 256, nbytes, dtype=np.uint8)), True, mod, n)
+        c = through_channel(orc, rng, tx, span, int(rng.integers(1, 60)), (rng.random() * 1.6 - 0.8) * np.pi / S, 34.0, data_start=10 * S)
+        if f == 0:
+            c[flen - 2 * S:] = 0                      # ends two symbols early: fewer live symbols than the others
+        if f == 3:
+            c = fc32(0.05 * (rng.standard_normal(span) + 1j * rng.standard_normal(span)))      # a dead frame in the middle too
+        caps.append(c)
+    caps = np.stack(caps)
+    res = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=max_sym).items()}
+    assert ("k_demod4096<frame>" if n == 4096 else "k_demod_mid<frame>") in ctx.last_dispatch(), ctx.last_dispatch()
+    n_ok = 0
+    for f in range(caps.shape[0]):
+        w = orc.decode_sc(wide(caps[f]), True, mod, n, max_symbols=max_sym, want_soft=True)
+        assert res["status"][f] == w["status"], (f, res["status"][f], w["status"])
+        if w["status"] != 0:
+            assert res["len"][f] == 0
+            continue
+        n_ok += 1
+        assert res["offset"][f] == w["offset"]
+        got = bytes(res["bytes"][f][: res["len"][f]])
+        if got != w["bytes"]:
+            assert len(got) == len(w["bytes"]), (f, len(got), len(w["bytes"]))
+            gb = np.unpackbits(np.frombuffer(got, np.uint8), bitorder="little")
+            wb = np.unpackbits(np.frombuffer(w["bytes"], np.uint8), bitorder="little")
+            pts = np.unique((128 + np.nonzero(gb != wb)[0]) // mod)
+            from util import decision_margin
+            assert np.all(decision_margin(np.asarray(w["soft"])[pts], mod) < TOL), (f, pts[:8])
+    assert res["status"][0] == -2 and res["status"][4] == -2 and n_ok >= 4
+
+
+def _misaligned_u8(ctx, n, nb):
+    import torch
+    buf = torch.zeros(n * nb + 8, dtype=torch.uint8, device=ctx.device)
+    out = buf[1:1 + n * nb].view(n, nb)
+    assert out.data_ptr() % 4 == 1 and out.is_contiguous()
+    return out
+
+
+def _misaligned_c64(ctx, rows, cols):
+    import torch
+    buf = torch.zeros(rows * cols + 4, dtype=torch.complex64, device=ctx.device)
+    out = buf[1:1 + rows * cols].view(rows, cols)
+    assert out.data_ptr() % 16 == 8 and out.is_contiguous()
+    return out
+
+
+@pytest.mark.parametrize("n,mod", [(64, 6), (512, 4), (4096, 8)])
+def test_misaligned_outputs_take_the_generic_kernels_and_still_match(api, orc, n, mod):
+    """Every shape-specialised launcher declines requests outside its envelope (hipErrorNotSupported) and the C ABI falls
+    back to the generic k_sym.  One deliberately misaligned output per launcher -- a byte-misaligned row base for the RX
+    demodulators (k_demod64 / k_demod_mid / k_demod4096), an 8-byte-aligned sample buffer for the TX stream kernels
+    (k_tx_mid / k_tx4096) and the one-pass encoders (k_txframe64 / k_txframe_mid / k_txframe4096) -- must (a) be reported
+    as served by the generic kernel and (b) still equal the oracle.  The aligned twin of each call must report the
+    specialised kernel: removing a run_* call from ofdm_abi.hip turns this red.  src/receiver.rs:99-190, src/transmitter.rs:11-58."""
+    import torch
+    rng = np.random.default_rng(n + mod)
+    guard = True
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    S, k, nf = n + n // 4, 8, 5
+    fast_rx = {64: "k_demod64", 512: "k_demod_mid", 4096: "k_demod4096"}[n]
+    fast_tx = "k_tx4096" if n == 4096 else "k_tx_mid"
+    fast_enc = {64: "k_txframe64", 512: "k_txframe_mid", 4096: "k_txframe4096"}[n]
+    # ---- RX demod
+    x, data = make_symbols_np(orc, rng, k * nf, n, guard, mod, snr_db=38.0)
+    want, wsoft = orc.rx_demod(wide(x), n, guard, mod, want_soft=True)
+    xs = dev(ctx, x.reshape(nf, k * S))
+    a = host(ctx.rx_demod(xs, k))
+    assert ctx.last_dispatch() == fast_rx
+    b = host(ctx.rx_demod(xs, k, out=_misaligned_u8(ctx, nf, k * ctx.bytes_per_symbol)))
+    assert ctx.last_dispatch() == "k_sym<demod>"
+    for got, what in ((a, fast_rx), (b, "k_sym")):
+        assert_bytes_match(bytes(got.ravel()), want, wsoft, mod, what=what)
+    # ---- TX symbol stream
+    n_sym = 9
+    nb = n_sym * ctx.bytes_per_symbol - 5
+    stream = rng.integers(0, 256, nb, dtype=np.uint8)
+    sd = torch.from_numpy(stream.copy()).to(ctx.device)
+    nd = ctx.data_carriers
+    opts = np.asarray(orc.modulate(bytes(stream), mod))
+    pts = np.zeros(n_sym * nd, np.complex128); pts[: opts.size] = opts
+    wtx = np.stack([orc.prefix_block(orc.encode_block(pts[i * nd:(i + 1) * nd], n, guard)[0]) for i in range(n_sym)])
+    a = host(ctx.tx_symbols(sd, n_sym=n_sym))
+    assert ctx.last_dispatch() == fast_tx
+    b = host(ctx.tx_symbols(sd, n_sym=n_sym, out=_misaligned_c64(ctx, n_sym, S)))
+    assert ctx.last_dispatch() == "k_sym<tx>"
+    assert rel_err(a, wtx) < TOL and rel_err(b, wtx) < TOL
+    # ---- encode
+    nbytes = 300 if n == 64 else 900
+    pay = rng.integers(0, 256, (3, nbytes), dtype=np.uint8)
+    pd = torch.from_numpy(pay).to(ctx.device)
+    a = host(ctx.encode_batch(pd))
+    assert ctx.last_dispatch() == fast_enc
+    b = host(ctx.encode_batch(pd, out=_misaligned_c64(ctx, 3, ctx.frame_samples(nbytes))))
+    assert ctx.last_dispatch() == "k_sym<tx>+k_tx_finish"
+    for f in range(3):
+        wf = orc.encode(bytes(pay[f]), guard, mod, n)
+        assert rel_err(a[f], wf) <= TOL and rel_err(b[f], wf) <= TOL
+    # ---- the A/B switches route to the generic kernels as well, per context
+    for key in ("no_fast64", "no_mid_kernels", "no_demod4096", "no_txframe64"):
+        ctx.set_tuning(key, 1)
+    c = host(ctx.rx_demod(xs, k))
+    assert ctx.last_dispatch() == "k_sym<demod>"
+    assert_bytes_match(bytes(c.ravel()), want, wsoft, mod, what="tuned off")
+    with pytest.raises(api.OfdmError):
+        ctx.set_tuning("no_such_key", 1)
+    with pytest.raises(api.OfdmError):
+        ctx.set_tuning("debug_demod64", 1)        # the ablation branches exist in the profile build only
+    assert ctx.get_tuning("profile_build") == 0 and ctx.get_tuning("no_fast64") == 1
 
 
 # ------------------------------------------------------------------ a24: channel (src/channel.rs:33-74) on the GPU

@@ -2,7 +2,7 @@
 integer delay, a random signed CFO and 30 dB noise; full RX chain (timing -> CFO -> channel estimate -> FFT -> equalise ->
 pilot phase -> demap -> length header) on one GPU.  Reports
   * the chain searching EVERY lag of every slot (the headline of this block) and bounded to the slot's 256 possible lags,
-    staged (two HBM passes) and through the one-pass kernel (OFDM_ONE_PASS_RX=1),
+    staged (two HBM passes) and through the one-pass kernel (ofdm_params.rx_path = OFDM_RX_ONE_PASS),
   * the Schmidl-Cox kernel alone against the HBM roofline (north-star target >= 40 %),
   * the TX side (encode) for the same payloads,
   * a CPU baseline (the oracle's decode_sc on a bounded sample, all host cores) and GPU-vs-CPU equality on that sample.
@@ -37,13 +37,9 @@ def synth(api, torch, ctx, n_frames, span=SPAN, snr_db=30.0, seed=3):
     return x, payload
 
 
-def _timed(ctx, torch, fn, steps):
-    fn()
-    torch.cuda.synchronize()
-    ctx.timer_start()
-    for _ in range(steps):
-        r = fn()
-    return ctx.timer_stop_ms() / steps, r
+def _timed(ctx, torch, fn, steps, grp=None):
+    from tools import rank_timing
+    return rank_timing.timed(ctx, torch, fn, steps, grp)
 
 
 def _ber(torch, res, payload):
@@ -98,31 +94,38 @@ def cpu_leg(x, payload, gpu, D, n_sample, threads):
             "cpu_ber_on_sample": cpu_bits / max(1, cpu_ok * NBYTES * 8)}
 
 
-def run(api, torch, n_frames, steps, device, cpu=True):
+def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
+    """grp (ofdm_amd.dist.Group, optional): every rank decodes its OWN n_frames captures (weak scaling, no data-path
+    collective); times are the max over ranks, rates the aggregate over all ranks."""
+    W = 1 if grp is None else grp.world
+    rank = 0 if grp is None else grp.rank
     ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True, device=device)
-    x, payload = synth(api, torch, ctx, n_frames)
+    x, payload = synth(api, torch, ctx, n_frames, seed=3 + rank)
     D = ctx.data_symbols(NBYTES)
     chain_bytes = n_frames * (SPAN * 8 + NBYTES)  # algorithmic: the capture once + the decoded payload
     out = {"workload": "cfg3: 2080-sample 64QAM frames at stride 2176, delay 1..64, CFO +-0.95 pi/80, FIR CHANNEL, 30 dB noise "
-                       "(channel_batch = src/channel.rs:33-74 on the GPU)", "frames": n_frames}
+                       "(channel_batch = src/channel.rs:33-74 on the GPU)", "frames": n_frames, "n_gpus": W,
+           "frames_per_gpu": n_frames}
+
+    ctx.set_tuning("one_pass_rx", 0)
 
     def leg(name, lags, one_pass):
-        if one_pass:
-            os.environ["OFDM_ONE_PASS_RX"] = "1"
+        ctx.set_tuning("one_pass_rx", int(one_pass))
         try:
-            ms, r = _timed(ctx, torch, lambda: ctx.decode_batch(x, max_symbols=D, n_lags=lags), steps)
+            ms, per_rank, r = _timed(ctx, torch, lambda: ctx.decode_batch(x, max_symbols=D, n_lags=lags), steps, grp)
         finally:
-            os.environ.pop("OFDM_ONE_PASS_RX", None)
-        out[name] = {"ms": ms, "msamples_per_s": n_frames * SPAN / ms / 1e3, "hbm_passes": 1 if one_pass else 2,
+            ctx.set_tuning("one_pass_rx", 0)
+        out[name] = {"ms": ms, "ms_per_rank": per_rank, "msamples_per_s": W * n_frames * SPAN / ms / 1e3, "hbm_passes": 1 if one_pass else 2,
+                     "dispatch": ctx.last_dispatch(),
                      "roofline": {"bound": "hbm", "achieved": chain_bytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": chain_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                  "frac": chain_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "per": "GPU (slowest rank)",
                                   "algorithmic_bytes_per_launch": chain_bytes,
                                   "kernels": "k_sc_cf<256,2,3,6,true> (one pass)" if one_pass else
                                              "k_sc_cf + k_sc_post + k_rx_prepare + k_rxframe64<6,true>"}}
         return r
 
     full = leg("full_chain_all_lags", 0, False)
-    nok, ber = _ber(torch, full, payload)
+    nok, ber = _ber(torch, full, payload)  # this rank's frames (rank 0's in the report)
     out["frames_decoded"] = nok
     out["ber_decoded_frames_vs_tx_payload"] = ber
     bounded = leg("full_chain_bounded_256_lags", SYNC_LAGS, False)
@@ -139,26 +142,26 @@ def run(api, torch, n_frames, steps, device, cpu=True):
                                          & (one["len"] == full["len"])).all()),
         "frames_with_different_bytes": int((one["bytes"][:, :NBYTES] != full["bytes"][:, :NBYTES]).any(dim=1).sum()),
         "max_cfo_difference": float((one["f_delta"] - full["f_delta"]).abs().max())}
-    if cpu:
+    if cpu and rank == 0:
         from tools import cpu_baseline as cb
         threads = cb.host_threads()
-        out["cpu_baseline"] = cpu_leg(x, payload, full, D, min(n_frames, 1024 * threads), threads)
+        out["cpu_baseline"] = cpu_leg(x, payload, full, D, min(n_frames, 65536, 1024 * threads), threads)
         out["speedup_vs_cpu"] = out["full_chain_all_lags"]["msamples_per_s"] / out["cpu_baseline"]["value"]
     del full, bounded, one
     # --- TX side of the hot path: encode (modulate + encode_block + IFFT + CP + header + normalise) for the same payloads
     npay = min(n_frames, 262144)
     txo = ctx.encode_batch(payload[:npay])
-    tms, _ = _timed(ctx, torch, lambda: ctx.encode_batch(payload[:npay], out=txo), steps)
+    tms, _, _ = _timed(ctx, torch, lambda: ctx.encode_batch(payload[:npay], out=txo), steps, grp)
     tx_bytes = npay * (txo.shape[-1] * 8 + NBYTES)
-    out["tx_encode"] = {"kernel": "k_txframe64<6, true>", "frames": npay, "ms": tms, "msamples_per_s": npay * txo.shape[-1] / tms / 1e3,
+    out["tx_encode"] = {"kernel": "k_txframe64<6, true>", "frames": npay, "ms": tms, "msamples_per_s": W * npay * txo.shape[-1] / tms / 1e3,
                         "roofline": {"bound": "hbm", "achieved": tx_bytes / (tms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": tx_bytes / (tms / 1e3) / 1e9 / HBM_PEAK_GBS}}
     del txo
     # --- Schmidl-Cox kernel alone, every lag of every slot
-    sms, _ = _timed(ctx, torch, lambda: ctx.sc_correlate(x), steps)
+    sms, _, _ = _timed(ctx, torch, lambda: ctx.sc_correlate(x), steps, grp)
     sc_bytes = n_frames * (SPAN * 8 + 16)
     out["schmidl_cox"] = {"kernel": "k_sc_cf<256, 2, 4, 0> + k_sc_post (all 1857 lags of every 2176-sample slot)", "kernel_ms": sms,
-                          "msamples_per_s": n_frames * SPAN / sms / 1e3,
+                          "msamples_per_s": W * n_frames * SPAN / sms / 1e3,
                           "roofline": {"bound": "hbm", "achieved": sc_bytes / (sms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "frac": sc_bytes / (sms / 1e3) / 1e9 / HBM_PEAK_GBS}}
     return out

@@ -1,10 +1,12 @@
 """Full decode chain (Schmidl-Cox timing over every lag, CFO, channel estimate, demod, header) for transform lengths other than the
 two BASELINE frame shapes: frames from the library's TX through its GPU channel, decode_batch timed, payloads checked.
-  python tools/bench_decode_n.py [N ...]      (OFDM_NO_MID_KERNELS=1: the generic demodulator instead of k_demod_mid<FRAME>)"""
+  python tools/bench_decode_n.py [N ...]      (OFDM_TUNE=no_mid_kernels=1: the generic demodulator instead of k_demod_mid<FRAME>)"""
 import json, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ofdm_amd import api
+from tools import tune_env
+tune_env.install()
 
 for n in [int(a) for a in sys.argv[1:]] or [128, 512, 2048]:
     ctx = api.Context(n_fft=n, modulation=api.QAM64, guard_bands=True)

@@ -20,47 +20,54 @@ from ofdm_amd import api
 HBM_PEAK_GBS = 8000.0
 
 
-def _timed(ctx, fn, steps):
-    fn()
-    torch.cuda.synchronize()
-    ctx.timer_start()
-    for _ in range(steps):
-        r = fn()
-    return ctx.timer_stop_ms() / steps, r
+def _timed(ctx, fn, steps, grp=None):
+    from tools import rank_timing
+    ms, per_rank, r = rank_timing.timed(ctx, torch, fn, steps, grp)
+    return ms, r, per_rank
 
 
-def cfg5(n_sym=65536, steps=5, cpu=True):
-    ctx = api.Context(n_fft=4096, modulation=api.QAM256, guard_bands=True)
-    g = torch.Generator(device="cuda"); g.manual_seed(5)
+def cfg5(n_sym=65536, steps=5, cpu=True, grp=None, device=None):
+    """grp (ofdm_amd.dist.Group, optional): every rank runs its OWN continuous stream of n_sym symbols (BASELINE configs[4]:
+    "continuous stream, 8 x MI355X"); times are the max over ranks, rates the aggregate over all ranks."""
+    W = 1 if grp is None else grp.world
+    rank = 0 if grp is None else grp.rank
+    device = torch.cuda.current_device() if device is None else device
+    ctx = api.Context(n_fft=4096, modulation=api.QAM256, guard_bands=True, device=device)
+    g = torch.Generator(device=ctx.device); g.manual_seed(5 + rank)
     bps = ctx.bytes_per_symbol
     nb = n_sym * bps
-    pay = torch.randint(0, 256, (nb,), dtype=torch.uint8, device="cuda", generator=g)
+    pay = torch.randint(0, 256, (nb,), dtype=torch.uint8, device=ctx.device, generator=g)
 
     def tx_staged():
         pts = ctx.modulate(pay)
         bins = ctx.encode_block(pts.view(-1, ctx.data_carriers))
         return ctx.prefix_block(bins)
 
-    tx_staged_ms, x = _timed(ctx, tx_staged, 2)
-    xf = torch.empty((n_sym, ctx.S), dtype=torch.complex64, device="cuda")
-    tx_ms, _ = _timed(ctx, lambda: ctx.tx_symbols(pay, out=xf), steps)   # the same three stages in one pass (k_tx4096)
+    tx_staged_ms, x, _ = _timed(ctx, tx_staged, 2, grp)
+    xf = torch.empty((n_sym, ctx.S), dtype=torch.complex64, device=ctx.device)
+    tx_ms, _, tx_per_rank = _timed(ctx, lambda: ctx.tx_symbols(pay, out=xf), steps, grp)   # the same three stages in one pass (k_tx4096)
+    tx_disp = ctx.last_dispatch()
     same = float((xf.view(-1) - x.view(-1)).abs().max() / x.view(-1).abs().max())
     del x
-    out = torch.empty((1, nb), dtype=torch.uint8, device="cuda")
-    rx_ms, _ = _timed(ctx, lambda: ctx.rx_demod(xf.view(1, -1), syms_per_frame=n_sym, out=out), steps)
+    out = torch.empty((1, nb), dtype=torch.uint8, device=ctx.device)
+    rx_ms, _, rx_per_rank = _timed(ctx, lambda: ctx.rx_demod(xf.view(1, -1), syms_per_frame=n_sym, out=out), steps, grp)
+    rx_disp = ctx.last_dispatch()
     ok = bool((out.view(-1) == pay).all())
 
     def both():
         ctx.tx_symbols(pay, out=xf)
         return ctx.rx_demod(xf.view(1, -1), syms_per_frame=n_sym, out=out)
 
-    both_ms, _ = _timed(ctx, both, steps)
+    both_ms, _, both_per_rank = _timed(ctx, both, steps, grp)
     ns = n_sym * ctx.S
     tx_bytes, rx_bytes = ns * 8 + nb, ns * 8 + nb
     res = {"workload": "cfg5: N=4096 256QAM guard bands, continuous symbols, TX IFFT then RX FFT", "symbols": n_sym,
-           "samples": ns, "tx_ms": tx_ms, "rx_ms": rx_ms, "tx_then_rx_ms": both_ms,
-           "tx_msamples_per_s": ns / tx_ms / 1e3, "rx_msamples_per_s": ns / rx_ms / 1e3,
-           "tx_then_rx_msamples_per_s": ns / both_ms / 1e3, "tx_staged_ms": tx_staged_ms,
+           "n_gpus": W, "symbols_per_gpu": n_sym, "samples_per_gpu": ns,
+           "samples": W * ns, "tx_ms": tx_ms, "rx_ms": rx_ms, "tx_then_rx_ms": both_ms,
+           "tx_ms_per_rank": tx_per_rank, "rx_ms_per_rank": rx_per_rank, "tx_then_rx_ms_per_rank": both_per_rank,
+           "tx_msamples_per_s": W * ns / tx_ms / 1e3, "rx_msamples_per_s": W * ns / rx_ms / 1e3,
+           "tx_then_rx_msamples_per_s": W * ns / both_ms / 1e3, "tx_staged_ms": tx_staged_ms,
+           "dispatch": {"tx": tx_disp, "rx": rx_disp},
            "tx_fused_vs_staged_max_rel_err": same, "rx_bytes_equal_tx_payload": ok,
            "roofline_tx": {"bound": "hbm", "kernel": "ofdm::k_tx4096<true>", "achieved": tx_bytes / (tx_ms / 1e3) / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tx_bytes / (tx_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
@@ -68,7 +75,7 @@ def cfg5(n_sym=65536, steps=5, cpu=True):
            "roofline_rx": {"bound": "hbm", "kernel": "ofdm::k_demod4096<8, true>", "achieved": rx_bytes / (rx_ms / 1e3) / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rx_bytes / (rx_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                            "algorithmic_bytes_per_launch": rx_bytes}}
-    if cpu:
+    if cpu and rank == 0:
         from oracle import oracle as orc
         from tools import cpu_baseline as cb
 
@@ -103,48 +110,55 @@ def cfg5(n_sym=65536, steps=5, cpu=True):
 CFG4_NBYTES = 1304  # -> 2282 coded bytes + 16-byte header = 4 data symbols of 576 B: the 17 920-sample frame BASELINE.md suggests
 
 
-def cfg4(n_frames=65536, total_frames=10_000_000, cpu=True, snr_db=40.0):
-    ctx = api.Context(n_fft=1024, modulation=api.QAM64, guard_bands=True, ecc=api.ECC_HAMMING74)
-    g = torch.Generator(device="cuda"); g.manual_seed(4)
-    pay = torch.randint(0, 256, (n_frames, CFG4_NBYTES), dtype=torch.uint8, device="cuda", generator=g)
+def cfg4(n_frames=65536, total_frames=10_000_000, cpu=True, snr_db=40.0, grp=None, device=None):
+    """grp (ofdm_amd.dist.Group, optional): BASELINE configs[3] is "10M-frame stream, frame-sharded across 8 x MI355X" -- rank r of R
+    owns frames [r F / R, (r + 1) F / R) of the stream (ofdm_amd.dist.shard_range) and counts them by passes over its OWN
+    resident ring of n_frames frames; no data-path collective.  Times are the max over ranks, rates the aggregate."""
+    from ofdm_amd.dist import shard_range
+    W = 1 if grp is None else grp.world
+    rank = 0 if grp is None else grp.rank
+    device = torch.cuda.current_device() if device is None else device
+    ctx = api.Context(n_fft=1024, modulation=api.QAM64, guard_bands=True, ecc=api.ECC_HAMMING74, device=device)
+    g = torch.Generator(device=ctx.device); g.manual_seed(4 + rank)
+    pay = torch.randint(0, 256, (n_frames, CFG4_NBYTES), dtype=torch.uint8, device=ctx.device, generator=g)
     D = ctx.data_symbols(CFG4_NBYTES)
     flen = ctx.frame_samples(CFG4_NBYTES)
     span = flen + 256
-    x = torch.empty((n_frames, span), dtype=torch.complex64, device="cuda")
+    x = torch.empty((n_frames, span), dtype=torch.complex64, device=ctx.device)
     chunk = 8192
     for lo in range(0, n_frames, chunk):
         hi = min(lo + chunk, n_frames)
         tx = ctx.encode_batch(pay[lo:hi].contiguous())
-        d = torch.randint(1, 65, (hi - lo,), device="cuda", generator=g, dtype=torch.int32)
-        fd = (torch.rand((hi - lo,), device="cuda", generator=g, dtype=torch.float64) * 1.9 - 0.95) * math.pi / ctx.S
-        ctx.channel_batch(tx, snr_db=snr_db, seed=4_000_003 + lo, delay=d, f_delta=fd, out=x[lo:hi])
+        d = torch.randint(1, 65, (hi - lo,), device=ctx.device, generator=g, dtype=torch.int32)
+        fd = (torch.rand((hi - lo,), device=ctx.device, generator=g, dtype=torch.float64) * 1.9 - 0.95) * math.pi / ctx.S
+        ctx.channel_batch(tx, snr_db=snr_db, seed=4_000_003 + lo + 1_000_000_007 * rank, delay=d, f_delta=fd, out=x[lo:hi])
         del tx
     torch.cuda.synchronize()
-    passes = max(1, -(-total_frames // n_frames))
+    lo_f, hi_f = shard_range(total_frames, rank, W)          # this rank's share of the stream
+    my_frames = hi_f - lo_f
+    passes = max(1, -(-my_frames // n_frames))
     res = {"workload": f"cfg4: N=1024 64QAM + Hamming(7,4), frames of {flen} samples in {span}-sample slots, FIR CHANNEL, delay 1..64, "
                        f"CFO +-0.95 pi/1280, {snr_db:g} dB (channel.rs definition), full RX chain",
-           "ring_frames": n_frames, "passes": passes, "frames_counted": passes * n_frames, "data_symbols": D}
+           "n_gpus": W, "stream_frames": total_frames, "stream_frames_this_rank": my_frames,
+           "ring_frames": n_frames, "passes": passes, "frames_counted": W * passes * n_frames, "data_symbols": D}
     chain_bytes = n_frames * (span * 8 + CFG4_NBYTES)
     for name, lags in (("full_chain_all_lags", 0), ("full_chain_bounded_2048_lags", 2048)):
-        r = ctx.decode_batch(x, max_symbols=D, n_lags=lags)
-        torch.cuda.synchronize()
-        ctx.timer_start()
-        for _ in range(passes):
-            r = ctx.decode_batch(x, max_symbols=D, n_lags=lags)
-        ms = ctx.timer_stop_ms() / passes
+        ms, r, per_rank = _timed(ctx, lambda: ctx.decode_batch(x, max_symbols=D, n_lags=lags), passes, grp)
         ok = (r["status"] == 0) & (r["len"] >= CFG4_NBYTES)
         good = int(((r["bytes"][:, :CFG4_NBYTES] == pay).all(dim=1) & ok).sum())
         diff = torch.bitwise_xor(r["bytes"][:, :CFG4_NBYTES], pay)[ok]
         bits = sum(int(((diff >> sh) & 1).sum()) for sh in range(8))
-        res[name] = {"ms_per_pass": ms, "stream_seconds": ms * passes / 1e3, "msamples_per_s": n_frames * span / ms / 1e3,
+        res[name] = {"ms_per_pass": ms, "ms_per_pass_per_rank": per_rank, "stream_seconds": ms * passes / 1e3,
+                     "msamples_per_s": W * n_frames * span / ms / 1e3, "dispatch": ctx.last_dispatch(),
                      "frames_synchronised": int(ok.sum()), "frames_decoded_exactly": good,
                      "ber_after_hamming_vs_tx_payload": bits / max(1, int(ok.sum()) * CFG4_NBYTES * 8),
                      "roofline": {"bound": "hbm", "achieved": chain_bytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": chain_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": chain_bytes,
+                                  "per": "GPU (slowest rank)",
                                   "kernels": "Schmidl-Cox (L = 1280) + k_rx_prepare + k_rxframe1024<6,true> + k_rx_finish (Hamming)"}}
         if lags == 0:
             full = r
-    if cpu:
+    if cpu and rank == 0:
         from oracle import oracle as orc
         from tools import cpu_baseline as cb
 

@@ -45,7 +45,7 @@ def one(n_fft, mod, total, steps, k, rx=True):
                   "rx_bytes_equal_tx_payload": bool((out.reshape(-1) == data).all())})
         del out
     del x
-    # frame-level TX (encode: header blocks + D data symbols, normalised per frame) and the staged chain behind OFDM_NO_MID_KERNELS
+    # frame-level TX (encode: header blocks + D data symbols, normalised per frame) and the staged chain behind OFDM_TUNE=no_mid_kernels=1
     D = 16
     nbytes = D * ctx.bytes_per_symbol - 16
     fs = ctx.frame_samples(nbytes)

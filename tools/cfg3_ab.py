@@ -1,5 +1,5 @@
 """A/B of the config-3 receive chain on one GPU: the one-pass kernel (k_sc_cf<..., BPS>) against the staged chain
-(the default; the one-pass kernel is OFDM_ONE_PASS_RX=1), same frames, outputs compared.  python tools/cfg3_ab.py [frames] [steps]"""
+(ofdm_params.rx_path = OFDM_RX_STAGED / OFDM_RX_ONE_PASS), same frames, outputs compared.  python tools/cfg3_ab.py [frames] [steps]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,14 +8,15 @@ from tools import bench_cfg3
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
+from tools import tune_env
+tune_env.install()
+ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True, rx_path=api.RX_STAGED)
+ctx1 = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True, rx_path=api.RX_ONE_PASS)
 x, payload = bench_cfg3.synth(api, torch, ctx, n, 2176)
 D = ctx.data_symbols(560)
 out = {}
 res = {}
-for name, env in (("one_pass", "1"), ("staged", None)):
-    if env: os.environ["OFDM_ONE_PASS_RX"] = env
-    else: os.environ.pop("OFDM_ONE_PASS_RX", None)
+for name, ctx in (("one_pass", ctx1), ("staged", ctx)):
     for lags in (0, 256):
         r = ctx.decode_batch(x, max_symbols=D, n_lags=lags)
         torch.cuda.synchronize()
@@ -25,7 +26,6 @@ for name, env in (("one_pass", "1"), ("staged", None)):
         res[(name, lags)] = {k: v.clone() for k, v in r.items()}
         out[f"{name}_lags{lags}_ms"] = ms
         out[f"{name}_lags{lags}_hbm_frac_one_read"] = n * (2176 * 8 + 560) / (ms / 1e3) / 8e12
-os.environ.pop("OFDM_ONE_PASS_RX", None)
 for lags in (0, 256):
     a, b = res[("one_pass", lags)], res[("staged", lags)]
     out[f"lags{lags}_status_equal"] = bool((a["status"] == b["status"]).all())

@@ -1,5 +1,5 @@
 """Quick A/B on one GPU: config-4 chain with the long-period Schmidl-Cox path (kernels_scbig.hip) against the round-1
-k_sc_tile path (OFDM_NO_SC_BIG=1), and config-5 TX / RX.  python tools/cfg45_ab.py [cfg4|cfg5]"""
+k_sc_tile path (tuning no_sc_big), and config-5 TX / RX.  python tools/cfg45_ab.py [cfg4|cfg5]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +15,8 @@ if which in ("cfg5", "both"):
 if which in ("cfg4", "both"):
     out["cfg4_scbig"] = brief(b.cfg4(16384, 65536, cpu=False))
     torch.cuda.empty_cache()
-    os.environ["OFDM_NO_SC_BIG"] = "1"
+    from ofdm_amd import api
+    api.DEFAULT_TUNING["no_sc_big"] = 1
     out["cfg4_sc_tile"] = brief(b.cfg4(16384, 65536, cpu=False))
-    os.environ.pop("OFDM_NO_SC_BIG")
+    api.DEFAULT_TUNING.pop("no_sc_big")
 print(json.dumps(out))

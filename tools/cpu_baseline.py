@@ -14,8 +14,14 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 
-def host_threads(cap=64):
-    return max(1, min(os.cpu_count() or 1, cap))
+def host_threads(cap=None):
+    """All host cores (hardware_concurrency); callers bound it only by the number of work units."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))  # the cores this process may actually run on (cgroup / taskset)
+    except (AttributeError, OSError):
+        pass
+    return max(1, n if cap is None else min(n, cap))
 
 
 def _pass(fn, blocks, reps):

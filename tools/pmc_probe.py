@@ -26,9 +26,9 @@ for _ in range(2):
     ctx.rx_demod(x2, syms_per_frame=16, out=out2)
     ctx.sc_correlate(x3)
     ctx.decode_batch(x3, max_symbols=16)
-    os.environ["OFDM_ONE_PASS_RX"] = "1"
+    ctx.set_tuning("one_pass_rx", 1)
     ctx.decode_batch(x3, max_symbols=16)
-    os.environ.pop("OFDM_ONE_PASS_RX")
+    ctx.set_tuning("one_pass_rx", 0)
     ctx.encode_batch(p3)
 torch.cuda.synchronize()
 info.update(fft_bytes_each_way=n * 16 * 512, demod_alg_read=n * 16 * 640, demod_write=n * 16 * 36, cfg3_capture_bytes=n * 2176 * 8,

@@ -2,19 +2,20 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ofdm_amd import api
+from ofdm_amd import _lib, api
 from tools import bench_cfg3
+_lib.use_profile_build()  # the section timers live in libofdm_hip_profile.so only
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
 x, _ = bench_cfg3.synth(api, torch, ctx, n, 2176)
 names = ["dma_wait", "(unused)", "phase1", "coarse", "fine", "fine.slide", "fine.select", "fine.exact"]
 for k, nm in enumerate(names):
-    os.environ["OFDM_SC_DEBUG"] = str(10 + k)
+    ctx.set_tuning("debug_sc", 10 + k)
     dh, _, _ = ctx.sc_correlate(x)
     torch.cuda.synchronize()
     d = dh.to(torch.float64)
     print(nm, "median", float(d.median()), "mean", float(d.mean()), "p90", float(d.quantile(0.9)))
-os.environ["OFDM_SC_DEBUG"] = "0"
+ctx.set_tuning("debug_sc", 0)
 ctx.timer_start()
 for _ in range(5): ctx.sc_correlate(x)
 print("ms per", n, "frames:", ctx.timer_stop_ms() / 5)

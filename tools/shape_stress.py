@@ -20,8 +20,7 @@ LENGTHS = (64, 128, 256, 512, 1024, 2048, 4096)
 for trial in range(trials):
     n = int(rng.choice(LENGTHS)); mod = int(rng.choice((1, 2, 4, 6, 8))); guard = bool(rng.integers(0, 2))
     S = n + n // 4
-    os.environ["OFDM_MID_GRID"] = str(int(rng.integers(1, 6)))     # few workgroups: many steps each
-    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard)
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard, tuning={"grid_cap": int(rng.integers(1, 6))})  # few workgroups: many steps each
     dev = lambda a: ctx.to_device(a)
     kind = int(rng.integers(0, 4))
     what = f"trial {trial}: N={n} mod={mod} guard={guard} kind={kind}"
@@ -86,6 +85,5 @@ for trial in range(trials):
         fails += 1
         print("FAIL", what, str(e)[:200], flush=True)
     ctx.close()
-os.environ.pop("OFDM_MID_GRID", None)
 print(f"{trials} trials: parity failures {fails}, excused boundary decisions {excused}")
 sys.exit(1 if fails else 0)
