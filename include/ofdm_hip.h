@@ -122,7 +122,7 @@ int ofdm_last_hip_error(const ofdm_ctx *ctx); /* raw hipError_t of the last fail
  * one ran.  Returns the full length of the string (like snprintf), buf receives at most n - 1 characters. Host call. */
 int ofdm_last_dispatch(const ofdm_ctx *ctx, char *buf, size_t n);
 /* Per-context tuning: A/B switches between kernel families and grid shapes.  The library reads NO environment variable.
- * Keys (value >= 0): "one_pass_rx" 0/1 (overrides ofdm_params.rx_path), "no_sc_big", "no_fast64", "no_demod4096",
+ * Keys (value >= 0): "one_pass_rx" 0/1 (overrides ofdm_params.rx_path), "no_sc_stream", "no_sc_big", "no_rx1024_finish", "no_fast64", "no_demod4096",
  * "no_mid_kernels", "no_rxframe1024", "no_txframe64" (1 = take the generic kernel instead of that family), "grid_cap"
  * (> 0: caps every persistent grid -- the tests use it to run many pipeline steps per workgroup on small batches),
  * "tx_waves", "sc_wg_per_cu", "demod64_wg_per_cu", "demod64_burst" (16 / 8 / 4 / 1), "demod64_narrow_stores",

@@ -16,8 +16,10 @@ constexpr bool kProfile = OFDM_PROFILE_BUILD != 0;
 // library reads no environment variable; a host that wants one maps it onto these keys itself (tools/tune_env.py).
 struct Tuning {
     int one_pass_rx = 0;           // N = 64 decode: timing + receive body in ONE kernel / HBM pass (k_sc_cf<..., BPS>) where it fits
+    int no_sc_stream = 0;          // L = 160 .. 1280: k_scb_chunks + k_scb_fine / k_sc_tile instead of the streaming detector
     int no_sc_big = 0;             // long-period Schmidl-Cox through k_sc_tile instead of k_scb_chunks + k_scb_fine
     int no_fast64 = 0, no_demod4096 = 0, no_mid_kernels = 0, no_rxframe1024 = 0, no_txframe64 = 0; // take the generic k_sym
+    int no_rx1024_finish = 0;      // k_rxframe1024 writes raw bytes and k_rx_finish runs as its own launch
     long long grid_cap = 0;        // > 0: caps every persistent grid (test hook: many steps per workgroup on a small batch)
     int tx_waves = 16;             // k_txframe64: wavefronts per CU
     int sc_wg_per_cu = 7;          // k_sc_cf: persistent workgroups per CU
@@ -102,8 +104,12 @@ struct Fast64Params {
 hipError_t run_demod64_fast(const SymParams &p, hipStream_t st, int num_cu);
 // N = 4096 RX demod as 64 x 64 (regular streams: no offset / CFO / per-frame symbol counts / soft output)
 hipError_t run_demod4096(const SymParams &p, hipStream_t st, int num_cu);
-// fused estimate_channel + per-symbol demod for N = 1024 frames (16 x 64 FFT), the N = 1024 analogue of run_rxframe64
-hipError_t run_rxframe1024(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu);
+// fused estimate_channel + per-symbol demod [+ finish] for N = 1024 frames (16 x 64 FFT, kernels_rx1024.hip), the N = 1024
+// analogue of run_rxframe64.  final_* (optional): length header, truncate and Hamming decode done by the same kernel when the
+// frame's packed bytes fit its LDS image; *fused_out reports whether they were (else the caller runs k_rx_finish).
+hipError_t run_rxframe1024(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu, unsigned char *final_out = nullptr,
+                           long long final_stride = 0, int32_t *final_len = nullptr, const int32_t *status = nullptr, int ecc = 0,
+                           bool *fused_out = nullptr);
 // N = 4096 continuous-stream TX (map + IFFT + CP) as 64 x 64; needs tx_raw_total >= 0
 hipError_t run_tx4096(const SymParams &p, hipStream_t st, int num_cu);
 hipError_t run_txframe4096(const SymParams &p, const float2 *header, float header_max, hipStream_t st, int num_cu);
@@ -166,6 +172,10 @@ struct ScRxFused {
 bool sc_rx_fused_ok(const ScParams &p, const ScRxFused &rx);
 hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st, const ScRxFused *rx = nullptr,
                        const int32_t **slow_list = nullptr, const int32_t **slow_count = nullptr);
+// periods L = 160 .. 1280 (N = 128 .. 1024): one streaming pass per frame that stops once the decision is determined
+// (kernels_scstream.hip)
+bool sc_stream_ok(const ScParams &p);
+hipError_t run_sc_stream(const ScParams &p, int num_cu, hipStream_t st);
 // long periods (N >= 128): chunk sums + bounded exact search (kernels_scbig.hip)
 struct ScBigParams {
     const float2 *in = nullptr;

@@ -2,7 +2,7 @@
 //   k_demod64      N = 64 RX demod for regular streams (BASELINE config 2, the headline)      -- described below
 //   k_rxframe64    N = 64 per-frame receive body after timing (config 3): channel estimate + demod [+ finish]
 //   k_txframe64    N = 64 encode: frame built in LDS, one HBM pass
-//   k_rxframe1024  N = 1024 per-frame receive body (config 4), FFT as 16 x 64
+//   (k_rxframe1024, the N = 1024 per-frame receive body of config 4, lives in kernels_rx1024.hip)
 //   k_demod4096 / k_tx4096   N = 4096 RX demod / continuous TX (config 5), FFT as 64 x 64
 //
 // k_demod64: CP strip + FFT64 + [equalise] + pilot phase + hard demap + LSB-first bit packing, for regularly spaced,
@@ -890,211 +890,6 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     }
 #undef OFDM_LAUNCH_4096_F
 #undef OFDM_LAUNCH_4096
-    return hipErrorNotSupported;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_rxframe1024: the per-frame RX body for N = 1024 after timing (BASELINE config 4), one 128-thread workgroup per
-// frame: estimate_channel on the 5 training blocks (summed in the time domain, ONE transform; 1/H stays in registers), then every live data symbol: CFO
-// derotation, CP strip + FFT1024, equalise, mean angle of the 64 pilots, hard demap, LSB-first packing.  The per-frame
-// scalars (offset, CFO, live symbols) are read once per frame and every symbol's samples are fetched while the previous
-// symbol is transformed.  The FFT is 16 x 64:
-//     X[c + 16 d] = sum_b W64^(b d) * [ W1024^(b c) * sum_a x[64 a + b] W16^(a c) ],  c < 16, d < 64
-//   stage A  lane pair (b, u): an 8-point butterfly over a = u + 2 m, then the radix-2 step across the pair (one DPP
-//            swap per value): FFT16 over a for column b (loads of 2 x 256 B per instruction);
-//   twiddle, transpose through LDS ([c][b], one barrier);
-//   stage B  the FFT64 over b for row c in the k_demod64 layout (wave-local).
-struct RxFrame1024Params {
-    const float2 *in;
-    long long n_frames, frame_stride, frame_len;
-    const int32_t *offset;
-    const double *f_delta;
-    const int32_t *nsym;
-    const float2 *tw;            // exp(-2 pi i m / 1024)
-    const float2 *inv_training;  // 1 / training[k]
-    unsigned char *out;
-    long long out_stride;
-    float2 *hk;                  // optional: channel estimate per frame (1024 bins)
-    int bps;
-};
-
-template <int BPS, bool GUARD>
-__global__ __launch_bounds__(128, 2) void k_rxframe1024(RxFrame1024Params p) {
-    constexpr int N = 1024, S = 1280, CP = 256, TS = 72, SLAB = 8 * 72;
-    __shared__ cf slab_all[2 * SLAB];
-    __shared__ cf T[16 * TS];
-    constexpr int ND = GUARD ? 48 * 16 : N;
-    constexpr int IMG_DW = ND * BPS / 32;            // packed bytes of one symbol, in dwords (<= 256)
-    __shared__ unsigned img[256];                    // the symbol's packed output image (bit fields OR-ed in)
-    __shared__ float red[2];
-    __shared__ cf ztab[8 * 128];  // [c'][thread]: W16^(u c') * ... stage-A twiddles, loop-invariant, kept out of the VGPRs
-    __shared__ cf w16tab[8 * 2];
-    __shared__ cf w64tab[7 * 8];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = tid >> 1, u = tid & 1;     // stage A roles
-    const int s = lane >> 3, t = lane & 7;   // stage B roles
-    const int row = 8 * wave + s;
-    cf *buf = slab_all + wave * SLAB + s * 72;
-    const int wr = swz(8 * t);
-
-    // W64^(r t), r = 1..7: LDS table [r-1][t]
-    // W16^(c') for the odd lane of a pair (1 for the even lane) and W1024^(b c), c = c' + 8 u: LDS tables
-#pragma unroll
-    for (int c = 0; c < 8; ++c) ztab[c * 128 + tid] = p.tw[b * (c + 8 * u)];
-    if (tid < 16) w16tab[tid] = (tid & 1) ? p.tw[64 * (tid >> 1)] : make_float2(1.f, 0.f);
-    if (tid < 56) w64tab[tid] = p.tw[16 * (tid / 8 + 1) * (tid & 7)];
-    __syncthreads();
-    auto bitoff = [&](int q) -> int { // bit offset of bin row + 16 d (d = t + 8 q) in the image, -1 = not a data bin
-        const int d = t + 8 * q;
-        return carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * 16 + row) * BPS : -1;
-    };
-    constexpr int nbytes = ND * BPS / 8;
-    // image -> global one symbol late (loads and stores share the in-order VM counter: stores issued just before the
-    // wait for the prefetched samples would be waited for too), clearing it for the next symbol
-    auto flush = [&](unsigned *dst) { for (int i = tid; i < IMG_DW; i += 128) { dst[i] = img[i]; img[i] = 0u; } };
-    for (int i = tid; i < 256; i += 128) img[i] = 0u;
-
-    for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
-        const int ns = p.nsym[f];
-        if (ns <= 0) continue; // workgroup-uniform
-        const long long off = p.offset ? p.offset[f] : 0;
-        const double turns = p.f_delta ? p.f_delta[f] * 0.15915494309189533577 : 0.0;
-        const cf st = cfo_phasor(turns, 128);
-        const cf *src = p.in + f * p.frame_stride + off;
-        const long long avail = p.frame_len - off; // samples of the trimmed frame
-        auto fetch = [&](int chunk, cf *dst) {     // stage-A samples of chunk `chunk` (zero past the capture: pad_chunk)
-            const long long n0 = (long long)chunk * S + CP + 64 * u + b;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) dst[m] = (n0 + 128 * m) < avail ? src[n0 + 128 * m] : make_float2(0.f, 0.f);
-        };
-        cf pre[8];
-        fetch(5, pre);
-        unsigned *pending = nullptr; // where the image currently in LDS belongs
-        cf g[8]; // first the time-domain sum of the derotated training blocks, then 1 / H
-#pragma unroll
-        for (int q = 0; q < 8; ++q) g[q] = make_float2(0.f, 0.f);
-        // steps -5 .. -1: training blocks (chunks 5 .. 9); steps 0 .. ns-1: data symbols (chunks 10 ..)
-        for (int k = -5; k < ns; ++k) {
-            const int chunk = 10 + k;
-            cf v[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = pre[m];
-            if (k + 1 < ns) fetch(chunk + 1, pre);
-            if (pending) { flush(pending); pending = nullptr; }
-            if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50)
-                cf ph = cfo_phasor(turns, (long long)chunk * S + CP + 64 * u + b);
-#pragma unroll
-                for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
-            }
-            if (k < 0) {
-                // estimate_channel (receiver.rs:212-229) averages the spectra of the 5 training blocks; the transform is linear, so
-                // the derotated blocks are summed in the time domain and transformed ONCE (as k_rxframe64 does): 5 transforms per
-                // frame instead of 9 for the 4-symbol frames of config 4.  (Measured: -10 % for this kernel, not -40 %: it waits for
-                // its loads, one memory round trip per block; issuing the training blocks' loads in batches spills ~40 registers.)
-#pragma unroll
-                for (int m = 0; m < 8; ++m) g[m] = cadd(g[m], v[m]);
-                if (k < -1) continue; // workgroup-uniform; no barrier has been passed in this step
-#pragma unroll
-                for (int m = 0; m < 8; ++m) v[m] = g[m];
-            }
-            // ---- stage A: FFT16 over a = u + 2 m  (8-point butterfly, then radix 2 across the lane pair)
-            bfly8<false>(v);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const cf e = cmul(v[c], w16tab[2 * c + u]);
-                const cf o = make_float2(dpp_f<0xB1>(e.x), dpp_f<0xB1>(e.y));   // the partner's value (lane ^ 1)
-                const cf y = u ? make_float2(o.x - e.x, o.y - e.y) : make_float2(e.x + o.x, e.y + o.y);
-                T[(c + 8 * u) * TS + b] = cmul(y, ztab[c * 128 + tid]);          // Y_b[c' + 8 u] * W1024^(b c)
-            }
-            __syncthreads();
-            // ---- stage B: FFT64 over b for row c
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = T[row * TS + t + 8 * m];
-            bfly8<false>(v);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
-#pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w64tab[(r - 1) * 8 + t]);
-            bfly8<false>(v);
-            // v[q] = X[row + 16 (t + 8 q)]
-            if (k < 0) { // k == -1: H = FFT(sum of the training blocks) / 5 / training
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int bin = row + 16 * (t + 8 * q);
-                    cf h = cmul(v[q], p.inv_training[bin]);
-                    h = make_float2(h.x * 0.2f, h.y * 0.2f);
-                    if (p.hk) p.hk[f * N + bin] = h;
-                    const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
-                    g[q] = make_float2(h.x * rn, -h.y * rn); // 1 / H
-                }
-                __syncthreads(); // T is rewritten by the next symbol
-                continue;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], g[q]); // equalise (receiver.rs:68-70)
-            if (GUARD) { // decode_block (receiver.rs:106-145): mean angle of the 4 x 16 pilots, rotate by -phase
-                cf pv = make_float2(1.f, 0.f);
-                pv = (t == 6) ? v[0] : pv;
-                pv = (t == 1) ? v[3] : pv;
-                pv = (t == 7) ? v[4] : pv;
-                pv = (t == 2) ? v[7] : pv;
-                float a = __ocml_atan2pi_f32(pv.y, pv.x);
-#pragma unroll
-                for (int sh = 32; sh >= 1; sh >>= 1) a += __shfl_xor(a, sh, 64);
-                if (lane == 0) red[wave] = a;
-                __syncthreads();
-                const float trn = (red[0] + red[1]) * (0.5f / 64.0f); // mean of the 64 pilot angles, in turns
-                const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { // demodulate + LSB-first packing: OR every field into the image
-                const int bo = bitoff(q);
-                if (bo >= 0) {
-                    const unsigned idx = demap_point(v[q], BPS);
-                    const int wd = bo >> 5, sh = bo & 31;
-                    atomicOr(&img[wd], idx << sh);
-                    if (BPS > 1 && (32 % BPS) != 0) {
-                        if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
-                    }
-                }
-            }
-            pending = reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes);
-            __syncthreads(); // image complete; T / red are reused by the next symbol
-        }
-        if (pending) flush(pending);
-        __syncthreads(); // the image is clear before the next frame ORs into it
-    }
-}
-
-// Fused channel estimate + demod for N = 1024 frames.  hipErrorNotSupported => caller uses run_chest + run_demod.
-hipError_t run_rxframe1024(const SymParams &sp, float2 *hk_out, hipStream_t st, int num_cu) {
-    if (!sp.nsym_frame || sp.soft) return hipErrorNotSupported;
-    const int nd = sp.guard ? 48 * 16 : 1024;
-    if ((nd * sp.bps / 8) % 4 != 0 || (reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
-    if (sp.n_frames <= 0) return hipSuccess;
-    RxFrame1024Params p;
-    p.in = sp.in; p.n_frames = sp.n_frames; p.frame_stride = sp.frame_stride; p.frame_len = sp.frame_len;
-    p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym = sp.nsym_frame; p.tw = sp.tw; p.inv_training = sp.inv_training;
-    p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.hk = hk_out; p.bps = sp.bps;
-    long long grid = (long long)num_cu * 7;
-    { const long long cap = tuning_or_default(sp.tune).grid_cap; if (cap > 0 && cap < grid) grid = cap; }
-    if (grid > p.n_frames) grid = p.n_frames;
-    trace_add(sp.trace, "k_rxframe1024");
-#define OFDM_LAUNCH_RX1024(B, G) { hipLaunchKernelGGL((k_rxframe1024<B, G>), dim3((unsigned)grid), dim3(128), 0, st, p); return hipGetLastError(); }
-    switch (sp.bps * 2 + (sp.guard ? 1 : 0)) {
-    case 2: OFDM_LAUNCH_RX1024(1, false) case 3: OFDM_LAUNCH_RX1024(1, true)
-    case 4: OFDM_LAUNCH_RX1024(2, false) case 5: OFDM_LAUNCH_RX1024(2, true)
-    case 8: OFDM_LAUNCH_RX1024(4, false) case 9: OFDM_LAUNCH_RX1024(4, true)
-    case 12: OFDM_LAUNCH_RX1024(6, false) case 13: OFDM_LAUNCH_RX1024(6, true)
-    case 16: OFDM_LAUNCH_RX1024(8, false) case 17: OFDM_LAUNCH_RX1024(8, true)
-    }
-#undef OFDM_LAUNCH_RX1024
     return hipErrorNotSupported;
 }
 

@@ -268,22 +268,6 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 
-// Workgroup barrier that does NOT drain the VM counter: the next tile's LDS-DMA stays in flight across it.
-// (__syncthreads() would emit s_waitcnt vmcnt(0) while a global_load_lds is outstanding.)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// One 1-KiB LDS-DMA piece: lane i copies 16 B from sbase + voff (per lane) to lds_byte_addr + 16 i.  Issued from
-// inline asm so that hipcc does not count it and drain it with vmcnt(0) before the next ds_read; the kernel waits
-// for it by hand (s_waitcnt vmcnt(0) at the top of the frame loop).
-__device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void *p) {
-    return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char *)p);
-}
-
 // Receive body fused behind the timing search (k_sc_cf<..., BPS != 0>): what k_sc_post + k_rx_prepare + k_rxframe64 +
 // k_rx_finish do in four more launches and a second HBM pass, done from the frame's LDS image.
 struct ScRxParams {

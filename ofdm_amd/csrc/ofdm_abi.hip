@@ -402,12 +402,14 @@ namespace {
 struct TuneKey { const char *name; int Tuning::*field; bool profile_only; };
 const TuneKey kTuneKeys[] = {
     {"one_pass_rx", &Tuning::one_pass_rx, false},
+    {"no_sc_stream", &Tuning::no_sc_stream, false},
     {"no_sc_big", &Tuning::no_sc_big, false},
     {"no_fast64", &Tuning::no_fast64, false},
     {"no_demod4096", &Tuning::no_demod4096, false},
     {"no_mid_kernels", &Tuning::no_mid_kernels, false},
     {"no_rxframe1024", &Tuning::no_rxframe1024, false},
     {"no_txframe64", &Tuning::no_txframe64, false},
+    {"no_rx1024_finish", &Tuning::no_rx1024_finish, false},
     {"tx_waves", &Tuning::tx_waves, false},
     {"sc_wg_per_cu", &Tuning::sc_wg_per_cu, false},
     {"demod64_wg_per_cu", &Tuning::demod64_wg_per_cu, false},
@@ -640,6 +642,12 @@ static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame
         int rc = ws_get(c, 6, sc_fast_workspace_bytes(n_frames, p.W), &wsp);
         if (rc) return rc;
         HIP_TRY(c, run_sc_fast(p, wsp, c->num_cu, c->stream));
+        return OFDM_OK;
+    }
+    // L = 160 .. 1280 (N = 128 .. 1024): ONE streaming pass per frame -- exact sums at every 10th lag from running prefixes, lag-by-lag
+    // evaluation only where a bound allows a crossing / a new maximum -- that stops once the peak window is closed (kernels_scstream.hip)
+    if (sc_stream_ok(p) && !c->tune.no_sc_stream) {
+        HIP_TRY(c, run_sc_stream(p, c->num_cu, c->stream));
         return OFDM_OK;
     }
     // long periods (N >= 128): one streaming pass for chunk sums, then an exact search only where the chunk bounds allow a
@@ -928,8 +936,11 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         p.in = x; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
         p.offset = offs; p.f_delta = fd; p.nsym_frame = (const int32_t *)w_nsym;
         p.out_bytes = (uint8_t *)w_raw; p.out_stride = raw_stride;
-        hipError_t e = off ? hipErrorNotSupported : run_rxframe1024(p, nullptr, c->stream, c->num_cu);
-        if (e == hipSuccess) fused = true;
+        // the kernel also parses the length header, truncates and Hamming-decodes into the caller's rows when they are 4-byte aligned
+        bool fin = false;
+        hipError_t e = off ? hipErrorNotSupported
+                           : run_rxframe1024(p, nullptr, c->stream, c->num_cu, out, out_stride, out_len, status, c->prm.ecc, &fin);
+        if (e == hipSuccess) { fused = true; finished = fin; }
         else if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }
     if (N == 64) {

@@ -775,6 +775,7 @@ def test_long_period_fine_tiles_agree(api):
     d = torch.randint(1, 1281, (nfr,), device=ctx.device, generator=g, dtype=torch.int32)
     fd = (torch.rand((nfr,), device=ctx.device, generator=g, dtype=torch.float64) * 1.8 - 0.9) * math.pi / ctx.S
     x = ctx.channel_batch(tx, snr_db=35.0, seed=9, delay=d, f_delta=fd, span=tx.shape[1] + 1536)
+    ctx.set_tuning("no_sc_stream", 1)            # N = 1024 is served by the streaming detector by default: this test is about the two-pass kernels
     small = [host(v) for v in ctx.sc_correlate(x)]
     assert ctx.last_dispatch() == "k_scb_chunks<contig>+k_scb_fine<5>"
     ctx.set_tuning("scb_big_tiles", 1)
@@ -783,6 +784,63 @@ def test_long_period_fine_tiles_agree(api):
     assert (small[0] >= 0).all() and np.array_equal(small[0], big[0])
     # the f64 sums are accumulated in a different order: equal to rounding, not to the bit
     assert np.abs(small[1] - big[1]).max() <= 1e-12 and np.abs(small[2] - big[2]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("reps", [3, 1, 2])
+@pytest.mark.parametrize("n", [128, 256, 512, 1024])
+def test_sc_stream_detector_against_the_oracle(api, orc, n, reps):
+    """k_sc_stream (kernels_scstream.hip): the one-pass, early-exit Schmidl-Cox detector for L = 160 .. 1280, against the oracle's
+    exhaustive search (orc_sc_sync) -- timing index bit-exact, CFO to 1e-9, metric to 1e-6 -- on a 2-wavefront grid (many frames per
+    wavefront, the DMA ring restarted per frame), with: packets at delays from 1 sample to most of a period (first crossing in the
+    first tiles and late), noise-only captures (the whole capture is streamed, no crossing), a packet so late that the capture
+    ends inside its peak window, captures cut inside the preamble, a strong and a weak packet in one capture (the FIRST crossing
+    wins), searches bounded to a few tiles, odd capture lengths, and window lengths W = L, 2 L, 3 L.  An 8-byte aligned batch
+    cannot use LDS-DMA and must be reported as served by the two-pass kernels.  (North-star extension: parity pinned by the
+    build's oracle only)"""
+    import torch
+    rng = np.random.default_rng(4242 + n + reps)
+    S = n + n // 4
+    W = reps * S
+    ctx = api.Context(n_fft=n, modulation=api.QAM16, guard_bands=True, sync_window_reps=reps, tuning={"grid_cap": 2})
+    nbytes = 40 * (n // 64)
+    txs = [orc.encode(bytes(rng.integers(0, 256, nbytes, dtype=np.uint8)), True, 4, n) for _ in range(3)]
+    flen = txs[0].size
+    span = (flen + 2 * S + 37) // 2 * 2 + (1 if n == 256 else 0)          # one length is odd (ragged last 16-byte piece)
+    caps = []
+    for f, delay in enumerate([1, 7, S // 3, S - 3, S + 11, 2 * S - 40]):
+        caps.append(through_channel(orc, rng, txs[f % 3], span, delay, (rng.random() * 1.6 - 0.8) * np.pi / S, 30.0, data_start=10 * S))
+    caps.append(fc32(0.05 * (rng.standard_normal(span) + 1j * rng.standard_normal(span))))                 # noise only
+    late = np.zeros(span, np.complex128)
+    late[span - 6 * S:] = txs[0][: 6 * S]                                                                   # the capture ends inside the window
+    caps.append(fc32(late + 0.003 * (rng.standard_normal(span) + 1j * rng.standard_normal(span))))
+    cut = caps[2].copy(); cut[int(3.4 * S):] = 0                                                           # ends inside the preamble
+    caps.append(cut)
+    two = 0.3 * wide(caps[1]) + np.roll(wide(caps[3]), 3 * S)                                              # weak early packet, strong late one
+    caps.append(fc32(two))
+    caps.append(np.zeros(span, np.complex64))                                                              # all zeros: no metric defined anywhere
+    caps = np.stack(caps)
+    xd = dev(ctx, caps)
+    aligned = xd.data_ptr() % 16 == 0 and span % 2 == 0
+    for lags in (0, 700, 2 * S + 5, 64):
+        d_hat, f_delta, metric = (host(v) for v in ctx.sc_correlate(xd, n_lags=lags))
+        disp = ctx.last_dispatch()
+        # short windows that fit one LDS tile (W + 20 <= 320: N = 128 with W = L) belong to the one-tile kernel k_sc_cf
+        fast = disp.startswith("k_sc_cf<")
+        assert fast or (disp == "k_sc_stream") == aligned, (disp, span)
+        assert not fast or W + 20 <= 320, (disp, W)
+        for f in range(caps.shape[0]):
+            wd, wp, wm, wfd = orc.sc_sync(wide(caps[f]), L=S, window_reps=reps, n_lags=lags, threshold=0.5)
+            assert d_hat[f] == wd, (n, reps, lags, f, int(d_hat[f]), wd)
+            if wd >= 0:
+                assert abs(f_delta[f] - wfd) <= 1e-9 and abs(metric[f] - wm) <= 1e-6 * max(1.0, wm), (n, reps, lags, f)
+    if aligned:   # the same captures one sample into a buffer: 8-byte aligned rows, no LDS-DMA
+        buf = torch.zeros(caps.size + 2, dtype=torch.complex64, device=ctx.device)
+        sh = buf[1:1 + caps.size].view(caps.shape)
+        sh.copy_(xd)
+        d2 = host(ctx.sc_correlate(sh)[0])
+        assert "k_sc_stream" not in ctx.last_dispatch() and "k_sc_cf" not in ctx.last_dispatch()
+        assert np.array_equal(d2, host(ctx.sc_correlate(xd)[0]))
+        assert ctx.last_dispatch() == "k_sc_stream" or W + 20 <= 320
 
 
 @pytest.mark.parametrize("n,mod,nbytes", [(128, 4, 300), (256, 6, 700), (512, 2, 500), (1024, 6, 1304), (2048, 4, 3000), (4096, 8, 9000)])
@@ -1033,6 +1091,70 @@ def test_rx_decode_dead_symbols_precede_live_ones(api, orc, n, mod, nbytes, grid
             from util import decision_margin
             assert np.all(decision_margin(np.asarray(w["soft"])[pts], mod) < TOL), (f, pts[:8])
     assert res["status"][0] == -2 and res["status"][4] == -2 and n_ok >= 4
+
+
+@pytest.mark.parametrize("ecc", [0, 1])
+@pytest.mark.parametrize("mod,guard", [(6, True), (4, False)])
+def test_rxframe1024_ring_across_frames_and_finish_modes(api, orc, mod, guard, ecc):
+    """k_rxframe1024 (kernels_rx1024.hip): the LDS-DMA sample ring runs ACROSS frames, so a 1- and a 2-workgroup grid make every
+    workgroup stream many frames back to back -- with dead frames (noise only: no sync) first, in the middle and last, a
+    capture cut inside a data symbol (that item takes the synchronous zero-filling path, pad_chunk receiver.rs:203-210), odd
+    and even start offsets (the one-sample shift of the aligned DMA image), and more symbols asked for than some frames hold.
+    Three ways through the kernel must give the oracle's bytes: the fused finish (header, truncate, Hamming decode from the LDS
+    image), raw bytes + k_rx_finish (tuning no_rx1024_finish), and an 8-byte-aligned batch (no LDS-DMA at all).
+    src/receiver.rs:44-95, 212-229."""
+    import torch
+    rng = np.random.default_rng(1024 + mod + ecc)
+    n, S = 1024, 1280
+    ctx0 = api.Context(n_fft=n, modulation=mod, guard_bands=guard, ecc=ecc)
+    nbytes = 1000
+    D = ctx0.data_symbols(nbytes)
+    flen = ctx0.frame_samples(nbytes)
+    span = (flen + S // 2 + 64) // 2 * 2
+    caps, offs = [], []
+    for f in range(11):
+        pay = bytes(rng.integers(0, 256, nbytes, dtype=np.uint8))
+        body = orc.hamming74_encode(pay) if ecc else pay
+        tx = orc.encode(body, guard, mod, n)
+        c = through_channel(orc, rng, tx, span, 3 + 5 * f, (rng.random() * 1.6 - 0.8) * np.pi / S, 35.0, data_start=10 * S)
+        if f in (0, 5, 10):
+            c = fc32(0.05 * (rng.standard_normal(span) + 1j * rng.standard_normal(span)))     # dead frames
+        if f == 7:
+            c[flen - S - 200:] = 0                                                            # ends inside the last-but-one data symbol
+        caps.append(c)
+    caps = np.stack(caps)
+    want = [orc.decode_sc(wide(caps[f]), guard, mod, n, max_symbols=D + 1, want_soft=True) for f in range(caps.shape[0])]
+    assert {w["offset"] & 1 for w in want if w["status"] == 0} == {0, 1}                       # both parities of the DMA shift
+    buf = torch.zeros(caps.size + 2, dtype=torch.complex64, device=ctx0.device)
+    shifted = buf[1:1 + caps.size].view(caps.shape)                                           # 8-byte aligned rows
+    shifted.copy_(torch.from_numpy(caps).to(ctx0.device))
+    assert shifted.data_ptr() % 16 == 8
+    for grid_cap in (1, 2):
+        for mode in ("fused", "unfused", "unaligned"):
+            tuning = {"grid_cap": grid_cap}
+            if mode == "unfused":
+                tuning["no_rx1024_finish"] = 1
+            ctx = api.Context(n_fft=n, modulation=mod, guard_bands=guard, ecc=ecc, tuning=tuning)
+            x = shifted if mode == "unaligned" else dev(ctx, caps)
+            res = {k: host(v) for k, v in ctx.decode_batch(x, max_symbols=D + 1).items()}
+            disp = ctx.last_dispatch()
+            assert ("k_rxframe1024<finish>" in disp) == (mode != "unfused") and ("k_rx_finish" in disp) == (mode == "unfused"), disp
+            for f, w in enumerate(want):
+                assert res["status"][f] == w["status"], (mode, grid_cap, f)
+                if w["status"] != 0:
+                    assert res["len"][f] == 0, (mode, grid_cap, f)
+                    continue
+                assert res["offset"][f] == w["offset"]
+                got = bytes(res["bytes"][f][: res["len"][f]])
+                wb = orc.hamming74_decode(w["bytes"])[0] if ecc else w["bytes"]
+                if got != wb:
+                    assert not ecc and len(got) == len(wb), (mode, grid_cap, f, len(got), len(wb))
+                    g1 = np.unpackbits(np.frombuffer(got, np.uint8), bitorder="little")
+                    w1 = np.unpackbits(np.frombuffer(wb, np.uint8), bitorder="little")
+                    pts = np.unique((128 + np.nonzero(g1 != w1)[0]) // mod)
+                    from util import decision_margin
+                    assert np.all(decision_margin(np.asarray(w["soft"])[pts], mod) < TOL), (mode, grid_cap, f)
+            assert int((res["status"] == 0).sum()) == 8 and list(res["status"][[0, 5, 10]]) == [-2, -2, -2]
 
 
 def _misaligned_u8(ctx, n, nb):
