@@ -95,10 +95,12 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
     for (int c = 0; c < 8; ++c) z[c] = p.tw[b * (c + 8 * u)];
     for (int i = tid; i < RX_RAW_DW; i += 128) raw[i] = 0u;
     __syncthreads();
-    auto bitoff = [&](int q) -> int { // bit offset of bin row + 16 d (d = t + 8 q) in the symbol's image, -1 = not a data bin
+    int bo8[8];                              // bit offset of bin row + 16 d (d = t + 8 q) in the symbol's image, -1 = not a data bin
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
         const int d = t + 8 * q;
-        return carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * 16 + row) * BPS : -1;
-    };
+        bo8[q] = carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * 16 + row) * BPS : -1;
+    }
 
     auto open_frame = [&](Cur &c, long long f) {
         while (f < p.n_frames && p.nsym[f] <= 0) {
@@ -193,9 +195,10 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         cf v[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = slotp[sh + 64 * u + 128 * m + b];
-        if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50); phase reduced in f64
-            cf ph = cfo_phasor(cc.turns, (long long)(10 + step) * S + CP + 64 * u + b);
-            const cf st = cfo_phasor(cc.turns, 128);
+        const double turns = cc.turns;
+        if (p.f_delta && step >= 0) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50); phase reduced in f64
+            cf ph = cfo_phasor(turns, (long long)(10 + step) * S + CP + 64 * u + b);
+            const cf st = cfo_phasor(turns, 128);
 #pragma unroll
             for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
         }
@@ -206,12 +209,26 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         ++k;
         if (step < 0) {
             // estimate_channel (receiver.rs:212-229) averages the spectra of the 5 training blocks; the transform is linear, so
-            // the derotated blocks are summed in the time domain and transformed ONCE
+            // the derotated blocks are summed in the time domain and transformed ONCE.  The derotation of sample i of block b,
+            // exp(-j phi ((5 + b) S + CP + i)), splits into the block's own factor exp(-j phi S b) -- one uniform phasor per block --
+            // and a per-sample factor that is applied once, to the sum.
+            if (p.f_delta) {
+                const cf rb = cfo_phasor(turns, (long long)S * (step + 5));
 #pragma unroll
-            for (int m = 0; m < 8; ++m) g[m] = cadd(g[m], v[m]);
+                for (int m = 0; m < 8; ++m) g[m] = cadd(g[m], cmul(v[m], rb));
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) g[m] = cadd(g[m], v[m]);
+            }
             if (step < -1) continue; // workgroup-uniform
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = g[m];
+            if (p.f_delta) {
+                cf ph = cfo_phasor(turns, (long long)5 * S + CP + 64 * u + b);
+                const cf st = cfo_phasor(turns, 128);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
+            }
         }
         lds_barrier();                // B2: every thread has taken its samples out of the slot: it becomes the transpose buffer
         // ---- stage A: FFT16 over a = u + 2 m  (8-point butterfly, then radix 2 across the lane pair)
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         unsigned *img = fused ? raw + step * IMG_DW : raw;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { // demodulate + LSB-first packing: OR every field into the image
-            const int bo = bitoff(q);
+            const int bo = bo8[q];
             if (bo >= 0) {
                 const unsigned idx = demap_point(v[q], BPS);
                 const int wd = bo >> 5, shf = bo & 31;

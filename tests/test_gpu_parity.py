@@ -826,7 +826,7 @@ def test_sc_stream_detector_against_the_oracle(api, orc, n, reps):
         disp = ctx.last_dispatch()
         # short windows that fit one LDS tile (W + 20 <= 320: N = 128 with W = L) belong to the one-tile kernel k_sc_cf
         fast = disp.startswith("k_sc_cf<")
-        assert fast or (disp == "k_sc_stream") == aligned, (disp, span)
+        assert fast or disp.startswith("k_sc_stream") == aligned, (disp, span)
         assert not fast or W + 20 <= 320, (disp, W)
         for f in range(caps.shape[0]):
             wd, wp, wm, wfd = orc.sc_sync(wide(caps[f]), L=S, window_reps=reps, n_lags=lags, threshold=0.5)
@@ -840,7 +840,7 @@ def test_sc_stream_detector_against_the_oracle(api, orc, n, reps):
         d2 = host(ctx.sc_correlate(sh)[0])
         assert "k_sc_stream" not in ctx.last_dispatch() and "k_sc_cf" not in ctx.last_dispatch()
         assert np.array_equal(d2, host(ctx.sc_correlate(xd)[0]))
-        assert ctx.last_dispatch() == "k_sc_stream" or W + 20 <= 320
+        assert ctx.last_dispatch().startswith("k_sc_stream") or W + 20 <= 320
 
 
 @pytest.mark.parametrize("n,mod,nbytes", [(128, 4, 300), (256, 6, 700), (512, 2, 500), (1024, 6, 1304), (2048, 4, 3000), (4096, 8, 9000)])
