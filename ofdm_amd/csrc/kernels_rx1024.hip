@@ -74,7 +74,9 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
     constexpr int ND = GUARD ? 48 * 16 : N;
     constexpr int IMG_DW = ND * BPS / 32;            // packed bytes of one symbol, in dwords (<= 256)
     constexpr int nbytes = ND * BPS / 8;
-    __shared__ __align__(16) cf ring[3 * SLOT];
+    constexpr int RING = 2;                          // slots: the item being transformed + the next one in flight (a third slot -- two in
+                                                     // flight -- costs a workgroup per CU: measured slower)
+    __shared__ __align__(16) cf ring[RING * SLOT];
     __shared__ unsigned raw[RX_RAW_DW];              // fused: the frame's packed bytes; unfused: one symbol's image at [0, IMG_DW)
     __shared__ float red[2];
     __shared__ cf w16tab[8 * 2];
@@ -161,11 +163,11 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
     cc = ic;
     bool dma_cur = false, dma_next = false;   // how the item under the consume cursor / the one after it were staged
     bool have_next = false;
-    long long k = 0;                  // items consumed so far: item k lives in slot k % 3
+    long long k = 0;                  // items consumed so far: item k lives in slot k % RING
     if (ic.f < p.n_frames) {
         dma_cur = issue(ic, 0);
         advance(ic, true);
-        if (ic.f < p.n_frames) { dma_next = issue(ic, 1); have_next = true; advance(ic, true); }
+        if (RING == 3 && ic.f < p.n_frames) { dma_next = issue(ic, 1); have_next = true; advance(ic, true); }
     }
     unsigned *pending = nullptr;      // unfused mode: where the symbol image currently in LDS belongs
     cf g[8];                          // first the time-domain sum of the derotated training blocks, then 1 / H
@@ -175,14 +177,14 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
     while (cc.f < p.n_frames) {
         // ---- item k has landed: every piece this wavefront issued for it, then everyone's
         if (dma_cur) {
-            if (have_next && dma_next) { if (wave == 0) wait_vm<5>(); else wait_vm<4>(); }   // the next item's pieces stay in flight
+            if (RING == 3 && have_next && dma_next) { if (wave == 0) wait_vm<5>(); else wait_vm<4>(); }   // the next item's pieces stay in flight
             else wait_vm<0>();
         }
         lds_barrier();                // B1: item k's samples are visible; everyone is done with item k - 1 (its slot, T, red)
-        const int slot = (int)(k % 3);
+        const int slot = (int)(k % RING);
         // ---- the item two ahead goes into the slot item k - 1 has just left
         bool dma_issued = false, issued = false;
-        if (ic.f < p.n_frames) { dma_issued = issue(ic, (int)((k + 2) % 3)); issued = true; advance(ic, true); }
+        if (ic.f < p.n_frames) { dma_issued = issue(ic, (int)((k + RING - 1) % RING)); issued = true; advance(ic, true); }
         if (!fused && pending) {      // unfused: the previous symbol's image leaves for HBM, the LDS image is cleared
             for (int i = tid; i < IMG_DW; i += 128) { pending[i] = raw[i]; raw[i] = 0u; }
             pending = nullptr;
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         // rotate the bookkeeping now: everything below refers to (f, step, slotp) only
         const bool last_of_frame = step == ns - 1;
         advance(cc, false);
-        dma_cur = dma_next; dma_next = dma_issued; have_next = issued;
+        if (RING == 3) { dma_cur = dma_next; dma_next = dma_issued; have_next = issued; }
+        else dma_cur = dma_issued;
         ++k;
         if (step < 0) {
             // estimate_channel (receiver.rs:212-229) averages the spectra of the 5 training blocks; the transform is linear, so
@@ -367,7 +370,7 @@ hipError_t run_rxframe1024(const SymParams &sp, float2 *hk_out, hipStream_t st, 
                       sp.out_stride <= (long long)RX_RAW_DW * 4 && !tuning_or_default(sp.tune).no_rx1024_finish;
     if (fuse) { p.final_out = final_out; p.final_stride = final_stride; p.final_len = final_len; }
     if (fused_out) *fused_out = fuse;
-    long long grid = (long long)num_cu * 5;
+    long long grid = (long long)num_cu * 6;   // 22.6 KB of LDS and 167 VGPRs per 2-wavefront workgroup: six (three wavefronts per SIMD) per CU
     { const long long cap = tuning_or_default(sp.tune).grid_cap; if (cap > 0 && cap < grid) grid = cap; }
     if (grid > p.n_frames) grid = p.n_frames;
     trace_add(sp.trace, fuse ? "k_rxframe1024<finish>" : "k_rxframe1024");
