@@ -44,6 +44,9 @@ struct StParams {
     int32_t *d_hat;
     double *f_delta;
     float *metric;
+    int debug;   // profile build only (Tuning::debug_sc = 40 + i): metric[f] = s_memtime ticks of section i of the frame --
+                 // producer: 0 tile waits, 1 sums + scans, 2 barrier waits; consumer: 3 bounds + lists, 4 evaluations before the
+                 // crossing, 5 barrier waits, 6 closing the window; 7 the whole frame (consumer)
 };
 
 struct SSums { double pr, pi, e, r; };
@@ -112,17 +115,27 @@ __device__ __forceinline__ void st_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ
 
 } // namespace
 
-__global__ __launch_bounds__(64, 1) void k_sc_stream(StParams p) { // one wave per SIMD (the LDS rings allow 4 frames per CU at N = 1024): the whole unified register file, no spills
+// Two wavefronts per frame.  Wavefront 1, the PRODUCER, owns the DMA ring and does the micro-chunk sums and scans of tile i;
+// wavefront 0, the CONSUMER, does the bounds, the lists and the lag-by-lag evaluations of step i - 1 at the same time; one
+// workgroup barrier per tile separates them (the prefix rings hold 64 entries more than one step needs).  The consumer's
+// global-memory round trips (evaluations) stall only itself and, through the barrier, at most the tile in progress.
+// DELAY = L / 640 when that is 1 or 2: the partner micro-chunk L samples earlier is the one the producer's lane read DELAY tiles
+// ago and stays in its registers (the LDS ring then holds only the tile being read and two in flight); 0: re-read from the ring.
+template <int DELAY>
+__global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    cf *ring = reinterpret_cast<cf *>(smem);                                  // [p.ring] samples, index n % ring
+    cf *ring = reinterpret_cast<cf *>(smem);                                  // [p.ring] samples: tile s in slot s % ring_tiles
     double *Ep = reinterpret_cast<double *>(ring + p.ring);                   // [epn] exclusive prefix of e over micro-chunks, index j % epn
     double *Qr = Ep + p.epn;                                                  // [qn]  ... of q.re
     double *Qi = Qr + p.qn;                                                   // [qn]  ... of q.im
     double *lsum = Qi + p.qn;                                                 // [ST_LIVE][4] boundary sums of the live intervals
     int *lk = reinterpret_cast<int *>(lsum + 4 * ST_LIVE);                    // [ST_LIVE] their interval index
     float *lub = reinterpret_cast<float *>(lk + ST_LIVE);                     // [ST_LIVE] their bound
+    long long *ptk = reinterpret_cast<long long *>(lub + ST_LIVE + 8);        // [3] the producer's section ticks (profile build)
+    int *ctl = reinterpret_cast<int *>(lub + ST_LIVE);                        // [2][2], slot = iteration parity: {the frame is decided, tiles needed (s_stop)}
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int L = p.L, W = p.W, cL = L / 10, cW = W / 10, cWL = cW + cL;
     const long long n = p.n_lags;
     const double thr = p.threshold;
@@ -132,11 +145,17 @@ __global__ __launch_bounds__(64, 1) void k_sc_stream(StParams p) { // one wave p
     // tiles the search can need: the last lag's window plus the one extra micro-chunk of its interval's bound
     const long long last_sample = n - 1 + W + L + 20;
     const int s_max = (int)((last_sample + ST_T - 1) / ST_T);                 // tiles 0 .. s_max - 1
+    // The consumer has nothing to judge before step i0 - 1 (no interval index k = 64 s - cWL + lane is >= 0 yet), so neither role
+    // takes part in a barrier before iteration i0: the producer sums the first tiles of a frame while the consumer is still
+    // closing the previous frame's window (list + global memory only: the rings belong to the producer until barrier i0).
+    const int i0 = cWL > 63 ? (cWL - 63 + 63) / 64 : 0;
+    const bool prof = kProfile && p.debug >= 40;
+    auto now = [&]() -> long long { return prof ? (long long)__builtin_amdgcn_s_memtime() : 0; };
 
     for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
         const cf *frame = p.in + f * p.frame_stride;
-        // Stage tile s into ring slot s % ring_tiles.  Whole tiles inside the capture go by LDS-DMA; a tile that touches the end of
-        // the capture is loaded with bounds checks and stored through registers (zeros past frame_len).
+        // Stage tile s into ring slot s % ring_tiles (producer).  Whole tiles inside the capture go by LDS-DMA; a tile that touches
+        // the end of the capture is loaded with bounds checks and stored through registers (zeros past frame_len).
         auto issue = [&](int s, int slot_idx) -> bool {   // slot_idx = s % ring_tiles, kept incrementally by the caller
             const long long t0 = (long long)s * ST_T;
             const unsigned slot = (unsigned)slot_idx * (unsigned)(ST_T * sizeof(cf));
@@ -155,23 +174,37 @@ __global__ __launch_bounds__(64, 1) void k_sc_stream(StParams p) { // one wave p
             }
             return false;
         };
-        // Lag-by-lag evaluation of interval k (lags 10 k .. 10 k + 9) from its boundary sums; the 4 x 9 samples of the slide come from
-        // global memory (L2: this wavefront streamed them moments ago).  Over lags in [lo, hi]: the first lag with M >= threshold
-        // (INT_MAX: none) and the first maximum.
-        // from_cross: the maximum only counts lags from this interval's own first crossing on (the search before the crossing: the
-        // lane that holds the wavefront's lowest crossing then already has the candidates of the peak window's first interval).
+        // Lag-by-lag evaluation of interval k (lags 10 k .. 10 k + 9) from its boundary sums (consumer); the 4 x 9 samples of the slide
+        // come from global memory (L2 / MALL: the producer streamed them moments ago).  Over lags in [lo, hi]: the first lag with
+        // M >= threshold (INT_MAX: none) and the first maximum.  from_cross: the maximum only counts lags from this interval's own
+        // first crossing on (the search before the crossing: the lane that holds the wavefront's lowest crossing then already has
+        // the candidates of the peak window's first interval).
         auto eval_interval = [&](bool active, int k, SSums x, long long lo, long long hi, bool from_cross, int &cross, SCand &best) {
             cross = INT_MAX;
             best = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
             const long long d0 = 10LL * k;
+            // All 36 loads are UNCONDITIONAL, from an address that is always valid (the sample itself, or sample 0 of the frame for a
+            // lane / an index that must read as zero), and the zeros are selected afterwards: written as `cond ? frame[i] : 0` the
+            // compiler branches around every load and waits for it inside the branch -- 36 serialized round trips per evaluation
+            // (5-16 thousand cycles, measured) instead of one.
             cf s0[9], s1[9], s2[9], s3[9];
+            {
+                bool ok0[9], ok1[9], ok2[9], ok3[9];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const long long i0 = d0 + j, i1 = i0 + L, i2 = i0 + W, i3 = i2 + L;
-                s0[j] = (active && i0 < p.frame_len) ? frame[i0] : make_float2(0.f, 0.f);
-                s1[j] = (active && i1 < p.frame_len) ? frame[i1] : make_float2(0.f, 0.f);
-                s2[j] = (active && i2 < p.frame_len) ? frame[i2] : make_float2(0.f, 0.f);
-                s3[j] = (active && i3 < p.frame_len) ? frame[i3] : make_float2(0.f, 0.f);
+                for (int j = 0; j < 9; ++j) {
+                    const long long i0 = d0 + j, i1 = i0 + L, i2 = i0 + W, i3 = i2 + L;
+                    ok0[j] = active && i0 < p.frame_len; ok1[j] = active && i1 < p.frame_len;
+                    ok2[j] = active && i2 < p.frame_len; ok3[j] = active && i3 < p.frame_len;
+                    const cf *a0 = frame + (ok0[j] ? i0 : 0), *a1 = frame + (ok1[j] ? i1 : 0), *a2 = frame + (ok2[j] ? i2 : 0), *a3 = frame + (ok3[j] ? i3 : 0);
+                    s0[j] = *a0; s1[j] = *a1; s2[j] = *a2; s3[j] = *a3;
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    if (!ok0[j]) s0[j] = make_float2(0.f, 0.f);
+                    if (!ok1[j]) s1[j] = make_float2(0.f, 0.f);
+                    if (!ok2[j]) s2[j] = make_float2(0.f, 0.f);
+                    if (!ok3[j]) s3[j] = make_float2(0.f, 0.f);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
@@ -191,16 +224,23 @@ __global__ __launch_bounds__(64, 1) void k_sc_stream(StParams p) { // one wave p
             }
         };
 
-        // ---- per-frame state (wave-uniform)
+        // ---- producer state (wavefront 1)
         double run_e = 0.0, run_qr = 0.0, run_qi = 0.0;   // totals so far = Ep / Q at the next index
+        int issued = 0;                                   // tiles issued so far
+        bool dma0 = false, dma1 = false;                  // whether tiles s / s + 1 went by DMA
+        float4 xo[DELAY > 0 ? DELAY : 1][5];              // DELAY > 0: this lane's micro-chunks of the last DELAY tiles
+#pragma unroll
+        for (int dly = 0; dly < (DELAY > 0 ? DELAY : 1); ++dly)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) xo[dly][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // ---- consumer state (wavefront 0)
         long long d1 = -1, hi = n - 1;                    // first crossing; last lag of the peak window
         int k1 = 0, kE = INT_MAX;                         // interval of d1; interval of hi
         int n_live = 0;
-        SCand best = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};     // wave-uniform: the crossing's interval and every flushed list
+        SCand best = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};     // the crossing's interval and every flushed list
         SCand mybest = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};   // per lane: the exact boundary candidates this lane has met (merged once, at the end)
-        float best_lo = 0.f;                                  // wave-uniform LOWER bound of the best metric met so far (f32, rounded down): prunes the list
+        float best_lo = 0.f;                                  // LOWER bound of the best metric met so far (f32, rounded down): prunes the list
         bool done = false;
-        if (lane == 0) { Ep[0] = 0.0; Qr[0] = 0.0; Qi[0] = 0.0; }
         // evaluate every interval on the live list exactly, fold the result into `best`, empty the list
         auto flush_live = [&]() {
             st_fence();
@@ -215,174 +255,236 @@ __global__ __launch_bounds__(64, 1) void k_sc_stream(StParams p) { // one wave p
             st_fence();
         };
 
-        int issued = 0;                                   // tiles issued so far
-        bool dma0 = false, dma1 = false;                  // whether tiles s / s + 1 went by DMA
-        int s_stop = s_max;                               // tiles beyond this one are not needed (known once d1 is)
-        if (s_max > 0) { dma0 = issue(0, 0); issued = 1; }
-        if (s_max > 1) { dma1 = issue(1, 1 % ring_tiles); issued = 2; }
+        int s_stop = s_max;                               // tiles beyond this one are not needed (the consumer learns it with d1)
         // ring positions, advanced by one tile / 64 entries per step with a conditional wrap (no integer division in the loop)
-        int slot_s = 0;                                   // s % ring_tiles
-        int slot_i = 2 % ring_tiles;                      // (s + 2) % ring_tiles
-        int e_new = 0;                                    // (64 s) % epn: Ep entry ke + 1 goes to e_new + lane + 1
-        int q_new = p.qn - (cL % p.qn);                   // (64 s - cL) mod qn
+        int slot_s = 0;                                   // i % ring_tiles (producer)
+        int slot_i = 2 % ring_tiles;                      // (i + 2) % ring_tiles
+        int e_new = 0;                                    // (64 i) % epn: Ep entry ke + 1 goes to e_new + lane + 1
+        int q_new = p.qn - (cL % p.qn);                   // (64 i - cL) mod qn
         if (q_new == p.qn) q_new = 0;
-        int e_k = p.epn - (cWL % p.epn);                  // (64 s - cWL) mod epn: interval k = 64 s - cWL + lane
+        int e_k = p.epn - (cWL % p.epn);                  // (64 s - cWL) mod epn: interval k = 64 s - cWL + lane of the consumer's step s
         if (e_k == p.epn) e_k = 0;
         int q_k = p.qn - (cWL % p.qn);                    // (64 s - cWL) mod qn
         if (q_k == p.qn) q_k = 0;
-        for (int s = 0; s < s_stop && !done; ++s) {
-            // ---- tile s has landed (this wavefront issued every piece of it); the next one stays in flight
-            if (dma0) { if (issued > s + 1 && dma1) st_wait_vm<ST_PIECES>(); else st_wait_vm<0>(); }
+        // The two roles run the SAME sequence of barriers from two separate loops (one loop with the roles as branches makes the
+        // register allocator carry both roles' state through both bodies: 70 spilled registers, 1.8x slower, measured).
+        if (wave == 1) {
+            // the first two tiles go out before the frame's barrier: the ring belongs to the producer alone, and the consumer may
+            // still be closing the previous frame's window
+            st_wait_vm<0>();                              // (tiles of the previous frame issued beyond its last step)
+            if (s_max > 0) { dma0 = issue(0, 0); issued = 1; }
+            if (s_max > 1) { dma1 = issue(1, 1 % ring_tiles); issued = 2; }
+            if (lane == 0) { Ep[0] = 0.0; Qr[0] = 0.0; Qi[0] = 0.0; }   // (the consumer left the rings at the last barrier of the previous frame)
             st_fence();
-            bool dma2 = false;
-            if (issued == s + 2 && issued < s_stop) { dma2 = issue(issued, slot_i); ++issued; }   // two tiles ahead: its slot was left L + T samples ago
-            dma0 = dma1; dma1 = dma2;
-            // ---- micro-chunk sums: e over samples [10 ke, 10 ke + 10), q over [10 kq, ..) with partners L later (both inside the ring)
-            const int ke = 64 * s + lane, kq = ke - cL;
-            double se = 0.0, sqr = 0.0, sqi = 0.0;
-            {
-                const int ie = slot_s * ST_T + 10 * lane;
-                const float4 *pe = reinterpret_cast<const float4 *>(ring + ie);
-                float4 x[5];
+            long long pt0 = 0, pt1 = 0, pt2 = 0;
+#pragma clang loop unroll(disable)
+            for (int i = 0;; ++i) {
+                const long long ta = now();
+                long long tb = ta;
+                if (i < s_stop) {
+                // ---- PRODUCER, tile i: it has landed (this wavefront issued every piece of it); the next one stays in flight
+                if (dma0) { if (issued > i + 1 && dma1) st_wait_vm<ST_PIECES>(); else st_wait_vm<0>(); }
+                st_fence();
+                tb = now();
+                bool dma2 = false;
+                if (issued == i + 2 && issued < s_stop) { dma2 = issue(issued, slot_i); ++issued; }   // two tiles ahead, into a slot nobody reads any more
+                dma0 = dma1; dma1 = dma2;
+                // micro-chunk sums: e over samples [10 ke, 10 ke + 10) of this tile, q over [10 kq, ..) with partners L later (= this tile)
+                const int ke = 64 * i + lane, kq = ke - cL;
+                double se = 0.0, sqr = 0.0, sqi = 0.0;
+                {
+                    const int ie = slot_s * ST_T + 10 * lane;
+                    const float4 *pe = reinterpret_cast<const float4 *>(ring + ie);
+                    float4 x[5], y[5];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) x[i] = pe[i];
+                    for (int j = 0; j < 5; ++j) x[j] = pe[j];
+                    if (DELAY > 0) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const double ar = x[i].x, ai = x[i].y, cr = x[i].z, ci = x[i].w;
-                    se += ar * ar + ai * ai; se += cr * cr + ci * ci;
-                }
-                if (kq >= 0) {
-                    const int iq = st_wrap(ie - L + p.ring, p.ring);   // L < ring
-                    const float4 *pq = reinterpret_cast<const float4 *>(ring + iq);
+                        for (int j = 0; j < 5; ++j) y[j] = xo[DELAY - 1][j];
+                    } else if (kq >= 0) {
+                        const float4 *pq = reinterpret_cast<const float4 *>(ring + st_wrap(ie - L + p.ring, p.ring));   // L < ring
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        const float4 y = pq[i];     // r[n], r[n + 1]; x[i] = r[n + L], r[n + L + 1]
-                        const double ar = y.x, ai = y.y, br = x[i].x, bi = x[i].y, cr = y.z, ci = y.w, dr = x[i].z, di = x[i].w;
+                        for (int j = 0; j < 5; ++j) y[j] = pq[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) y[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {   // y = r[n], r[n + 1]; x = r[n + L], r[n + L + 1]
+                        const double br = x[j].x, bi = x[j].y, dr = x[j].z, di = x[j].w;
+                        const double ar = y[j].x, ai = y[j].y, cr = y[j].z, ci = y[j].w;
+                        se += br * br + bi * bi; se += dr * dr + di * di;
                         sqr += ar * br + ai * bi; sqi += ar * bi - ai * br;
                         sqr += cr * dr + ci * di; sqi += cr * di - ci * dr;
                     }
-                }
-            }
-            // inclusive scans -> prefix entries ke + 1 (Ep) and kq + 1 (Q)
-            const double pe_ = st_scan(se) + run_e, pqr = st_scan(sqr) + run_qr, pqi = st_scan(sqi) + run_qi;
-            Ep[st_wrap(e_new + lane + 1, p.epn)] = pe_;
-            if (kq >= 0) { const int j = st_wrap(q_new + lane + 1, p.qn); Qr[j] = pqr; Qi[j] = pqi; }
-            run_e = st_readlane(pe_, 63); run_qr = st_readlane(pqr, 63); run_qi = st_readlane(pqi, 63);
-            st_fence();
-            // ---- the 64 intervals whose bound became computable: k = 64 (s + 1) - cWL - 64 + lane
-            const int k = 64 * s - cWL + lane;
-            const bool valid = k >= 0 && 10LL * k < n;
-            SSums b = SSums{0, 0, 0, 0};
-            float ub = 0.f;
-            if (valid) {
-                // ring positions of k, k + cL, k + cW, k + cWL (each offset is below the ring size: one conditional wrap each)
-                const int e0 = st_wrap(e_k + lane, p.epn), eL = st_wrap(e0 + cL, p.epn), eW = st_wrap(e0 + cW, p.epn), eWL = st_wrap(eW + cL, p.epn);
-                const int q0 = st_wrap(q_k + lane, p.qn), qW = st_wrap(q0 + cW, p.qn);
-                const double E0 = Ep[e0], EL = Ep[eL], EW = Ep[eW], EWL = Ep[eWL];
-                b = SSums{Qr[qW] - Qr[q0], Qi[qW] - Qi[q0], EW - E0, EWL - EL};   // exact sums at lag 10 k
-                const double te0 = Ep[st_wrap(e0 + 1, p.epn)] - E0, teL = Ep[st_wrap(eL + 1, p.epn)] - EL,
-                             teW = Ep[st_wrap(eW + 1, p.epn)] - EW, teWL = Ep[st_wrap(eWL + 1, p.epn)] - EWL;
-                // The bound only has to be an UPPER bound: the exact f64 sums are rounded to f32 (6e-8 each), the square root, the
-                // reciprocal and the products are f32 (1 ulp each), and one factor 1.00001 covers all of it -- no f64 sqrt / divide
-                const float pm = __builtin_amdgcn_sqrtf((float)(b.pr * b.pr + b.pi * b.pi));
-                const float u = pm + 0.5f * (float)(te0 + teL + teW + teWL);
-                const float elo = (float)(b.e - te0), rlo = (float)(b.r - teL);
-                ub = 3.0e38f;
-                if (elo > 0.f && rlo > 0.f) { const float q = u * u * __builtin_amdgcn_rcpf(elo * rlo) * 1.00001f; ub = q < 3.0e38f ? q : 3.0e38f; }
-                if (!(u > 0.f)) ub = 0.f;   // an all-zero neighbourhood: no lag of this interval has a defined metric
-            }
-            const int k_hi = 64 * s - cWL + 63;               // the highest interval of this step (wave-uniform)
-            if (d1 < 0) {
-                // ---- before the crossing: intervals whose bound reaches the threshold are evaluated lag by lag
-                const bool flag = valid && ub >= thr_f;
-                if (__builtin_amdgcn_ballot_w64(flag)) {
-                    int cr; SCand c;
-                    eval_interval(flag, k, b, 0, n - 1, true, cr, c);
-                    int cmin = cr;
+                    if (DELAY > 0) {
 #pragma unroll
-                    for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(cmin, sft, 64); cmin = o < cmin ? o : cmin; }
-                    cmin = st_uni(cmin);
-                    if (cmin != INT_MAX) {
-                        d1 = cmin; k1 = (int)(d1 / 10);
-                        hi = d1 + W < n - 1 ? d1 + W : n - 1;
-                        kE = (int)(hi / 10);
-                        // the stream can stop once interval kE has had its bound: tile index of sample 10 (kE + cWL + 1) + 9
-                        const long long need = (10LL * (kE + cWL + 2) + ST_T - 1) / ST_T;
-                        if (need < s_stop) s_stop = (int)need;
-                        // the crossing's own interval, from the crossing on: held by the one lane whose first crossing is d1
-                        // (hi >= d1 + 9 unless the search ends inside this interval, where eval_interval's own range [0, n - 1] agrees)
-                        const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cr == cmin));
-                        best = sc_readlane(c, src);
-                        best_lo = (float)(best.num / best.den) * 0.99999f;
+                        for (int dly = DELAY - 1; dly > 0; --dly)
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) xo[dly][j] = xo[dly - 1][j];
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) xo[0][j] = x[j];
                     }
                 }
+                // inclusive scans -> prefix entries ke + 1 (Ep) and kq + 1 (Q)
+                const double pe_ = st_scan(se) + run_e, pqr = st_scan(sqr) + run_qr, pqi = st_scan(sqi) + run_qi;
+                Ep[st_wrap(e_new + lane + 1, p.epn)] = pe_;
+                if (kq >= 0) { const int j = st_wrap(q_new + lane + 1, p.qn); Qr[j] = pqr; Qi[j] = pqi; }
+                run_e = st_readlane(pe_, 63);
+                if (64 * i + 63 - cL >= 0) { run_qr = st_readlane(pqr, 63); run_qi = st_readlane(pqi, 63); }
+                slot_s = st_wrap(slot_s + 1, ring_tiles); slot_i = st_wrap(slot_i + 1, ring_tiles);
+                e_new = st_wrap(e_new + 64, p.epn); q_new = st_wrap(q_new + 64, p.qn);
             }
-            if (d1 >= 0) {
-                // ---- inside the peak window: boundaries are exact candidates (kept per lane, merged once when the window closes); an
-                //      interval stays alive while its bound can beat a lower bound of the best metric met so far
-                const bool inwin = valid && k > k1 && 10LL * k <= hi;
-                float mf = 0.f;
-                if (inwin) {
-                    const double num = b.pr * b.pr + b.pi * b.pi, den = b.e * b.r;
-                    if (den > 0.0) { mybest = sc_pick(mybest, SCand{num, den, b.pr, b.pi, 10 * k}); mf = (float)num * __builtin_amdgcn_rcpf((float)den); }
+                const long long tc = now();
+                if (i < i0) { if (prof) { pt0 += tb - ta; pt1 += tc - tb; } continue; }   // (i0 < s_max always: W + L + 20 samples take more than i0 tiles)
+                lds_barrier();   // tile i is summed, step i - 1 is judged
+                if (prof) { const long long td = now(); pt0 += tb - ta; pt1 += tc - tb; pt2 += td - tc; }
+                const int stop = __builtin_amdgcn_readfirstlane(ctl[2 * (i & 1)]);
+                s_stop = __builtin_amdgcn_readfirstlane(ctl[2 * (i & 1) + 1]);
+                if (stop || i >= s_stop) break;
+            }
+            if (prof && lane == 0) { ptk[0] = pt0; ptk[1] = pt1; ptk[2] = pt2; }
+        } else {
+            const long long t_frame = now();
+            long long ct3 = 0, ct4 = 0, ct5 = 0;
+            // ring positions of the consumer's first step, i0 - 1
+            for (int j = 0; j < i0 - 1; ++j) { e_k = st_wrap(e_k + 64, p.epn); q_k = st_wrap(q_k + 64, p.qn); }
+#pragma clang loop unroll(disable)
+            for (int i = i0;; ++i) {
+                const long long ta = now();
+                long long tev = 0;
+                if (i >= 1 && !done) {
+
+                // ---- CONSUMER, step s = i - 1: the 64 intervals whose bound became computable, k = 64 s - cWL + lane
+                const int s = i - 1;
+                const int k = 64 * s - cWL + lane;
+                const bool valid = k >= 0 && 10LL * k < n;
+                SSums b = SSums{0, 0, 0, 0};
+                float ub = 0.f;
+                if (valid) {
+                    // ring positions of k, k + cL, k + cW, k + cWL (each offset is below the ring size: one conditional wrap each)
+                    const int e0 = st_wrap(e_k + lane, p.epn), eL = st_wrap(e0 + cL, p.epn), eW = st_wrap(e0 + cW, p.epn), eWL = st_wrap(eW + cL, p.epn);
+                    const int q0 = st_wrap(q_k + lane, p.qn), qW = st_wrap(q0 + cW, p.qn);
+                    const double E0 = Ep[e0], EL = Ep[eL], EW = Ep[eW], EWL = Ep[eWL];
+                    b = SSums{Qr[qW] - Qr[q0], Qi[qW] - Qi[q0], EW - E0, EWL - EL};   // exact sums at lag 10 k
+                    const double te0 = Ep[st_wrap(e0 + 1, p.epn)] - E0, teL = Ep[st_wrap(eL + 1, p.epn)] - EL,
+                                 teW = Ep[st_wrap(eW + 1, p.epn)] - EW, teWL = Ep[st_wrap(eWL + 1, p.epn)] - EWL;
+                    // The bound only has to be an UPPER bound: the exact f64 sums are rounded to f32 (6e-8 each), the square root, the
+                    // reciprocal and the products are f32 (1 ulp each), and one factor 1.00001 covers all of it -- no f64 sqrt / divide
+                    const float pm = __builtin_amdgcn_sqrtf((float)(b.pr * b.pr + b.pi * b.pi));
+                    const float u = pm + 0.5f * (float)(te0 + teL + teW + teWL);
+                    const float elo = (float)(b.e - te0), rlo = (float)(b.r - teL);
+                    ub = 3.0e38f;
+                    if (elo > 0.f && rlo > 0.f) { const float q = u * u * __builtin_amdgcn_rcpf(elo * rlo) * 1.00001f; ub = q < 3.0e38f ? q : 3.0e38f; }
+                    if (!(u > 0.f)) ub = 0.f;   // an all-zero neighbourhood: no lag of this interval has a defined metric
                 }
-                best_lo = fmaxf(best_lo, st_wave_max(mf) * 0.99999f);
-                const float need = best_lo;
-                if (n_live > 0) {   // old entries that can still matter, compacted in place
-                    st_fence();
-                    const bool old = lane < n_live;
-                    const int ok_ = old ? lk[lane] : 0;
-                    const float oub = old ? lub[lane] : 0.f;
-                    SSums os = SSums{0, 0, 0, 0};
-                    if (old) os = SSums{lsum[4 * lane], lsum[4 * lane + 1], lsum[4 * lane + 2], lsum[4 * lane + 3]};
-                    const bool keep = old && oub >= need;
-                    const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
-                    if (__builtin_popcountll(km) != n_live) {
-                        const int pos = __builtin_popcountll(km & ((1ull << lane) - 1ull));
+                const int k_hi = 64 * s - cWL + 63;               // the highest interval of this step
+                if (d1 < 0) {
+                    // ---- before the crossing: intervals whose bound reaches the threshold are evaluated lag by lag
+                    const bool flag = valid && ub >= thr_f;
+                    if (__builtin_amdgcn_ballot_w64(flag)) {
+                        int cr; SCand c;
+                        const long long te_ = now();
+                        eval_interval(flag, k, b, 0, n - 1, true, cr, c);
+                        if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tev = now() - te_; }
+                        int cmin = cr;
+#pragma unroll
+                        for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(cmin, sft, 64); cmin = o < cmin ? o : cmin; }
+                        cmin = st_uni(cmin);
+                        if (cmin != INT_MAX) {
+                            d1 = cmin; k1 = (int)(d1 / 10);
+                            hi = d1 + W < n - 1 ? d1 + W : n - 1;
+                            kE = (int)(hi / 10);
+                            // the stream can stop once interval kE has had its bound: tiles up to sample 10 (kE + cWL + 2)
+                            const long long need = (10LL * (kE + cWL + 2) + ST_T - 1) / ST_T;
+                            if (need < s_stop) s_stop = need > s + 1 ? (int)need : s + 1;
+                            // the crossing's own interval, from the crossing on: held by the one lane whose first crossing is d1
+                            // (hi >= d1 + 9 unless the search ends inside this interval, where eval_interval's own range [0, n - 1] agrees)
+                            const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cr == cmin));
+                            best = sc_readlane(c, src);
+                            best_lo = (float)(best.num / best.den) * 0.99999f;
+                        }
+                    }
+                }
+                if (d1 >= 0) {
+                    // ---- inside the peak window: boundaries are exact candidates (kept per lane, merged once when the window closes); an
+                    //      interval stays alive while its bound can beat a lower bound of the best metric met so far
+                    const bool inwin = valid && k > k1 && 10LL * k <= hi;
+                    float mf = 0.f;
+                    if (inwin) {
+                        const double num = b.pr * b.pr + b.pi * b.pi, den = b.e * b.r;
+                        if (den > 0.0) { mybest = sc_pick(mybest, SCand{num, den, b.pr, b.pi, 10 * k}); mf = (float)num * __builtin_amdgcn_rcpf((float)den); }
+                    }
+                    best_lo = fmaxf(best_lo, st_wave_max(mf) * 0.99999f);
+                    const float need = best_lo;
+                    if (n_live > 0) {   // old entries that can still matter, compacted in place
                         st_fence();
-                        if (keep) { lk[pos] = ok_; lub[pos] = oub; lsum[4 * pos] = os.pr; lsum[4 * pos + 1] = os.pi; lsum[4 * pos + 2] = os.e; lsum[4 * pos + 3] = os.r; }
-                        n_live = __builtin_popcountll(km);
+                        const bool old = lane < n_live;
+                        const int ok_ = old ? lk[lane] : 0;
+                        const float oub = old ? lub[lane] : 0.f;
+                        SSums os = SSums{0, 0, 0, 0};
+                        if (old) os = SSums{lsum[4 * lane], lsum[4 * lane + 1], lsum[4 * lane + 2], lsum[4 * lane + 3]};
+                        const bool keep = old && oub >= need;
+                        const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+                        if (__builtin_popcountll(km) != n_live) {
+                            const int pos = __builtin_popcountll(km & ((1ull << lane) - 1ull));
+                            st_fence();
+                            if (keep) { lk[pos] = ok_; lub[pos] = oub; lsum[4 * pos] = os.pr; lsum[4 * pos + 1] = os.pi; lsum[4 * pos + 2] = os.e; lsum[4 * pos + 3] = os.r; }
+                            n_live = __builtin_popcountll(km);
+                            st_fence();
+                        }
+                    }
+                    // new intervals (their interior lags 10 k + 1 .. 10 k + 9, as far as they lie in the window)
+                    const bool add = inwin && ub >= need;
+                    unsigned long long am = __builtin_amdgcn_ballot_w64(add);
+                    while (am) {   // in batches that fit the list; a full list is evaluated exactly and emptied
+                        const int room = ST_LIVE - n_live;
+                        if (room == 0) { flush_live(); continue; }
+                        const int rank = __builtin_popcountll(am & ((1ull << lane) - 1ull));
+                        const bool take = add && ((am >> lane) & 1ull) && rank < room;
+                        if (take) {
+                            const int pos = n_live + rank;
+                            lk[pos] = k; lub[pos] = ub; lsum[4 * pos] = b.pr; lsum[4 * pos + 1] = b.pi; lsum[4 * pos + 2] = b.e; lsum[4 * pos + 3] = b.r;
+                        }
+                        const unsigned long long tm = __builtin_amdgcn_ballot_w64(take);
+                        n_live += __builtin_popcountll(tm);
+                        am &= ~tm;
                         st_fence();
                     }
+                    if (k_hi >= kE) done = true;   // every interval up to kE has been seen: the producer may stop and start the next frame
                 }
-                // new intervals (their interior lags 10 k + 1 .. 10 k + 9, as far as they lie in the window)
-                const bool add = inwin && ub >= need;
-                unsigned long long am = __builtin_amdgcn_ballot_w64(add);
-                while (am) {   // in batches that fit the list; a full list is evaluated exactly and emptied
-                    const int room = ST_LIVE - n_live;
-                    if (room == 0) { flush_live(); continue; }
-                    const int rank = __builtin_popcountll(am & ((1ull << lane) - 1ull));
-                    const bool take = add && ((am >> lane) & 1ull) && rank < room;
-                    if (take) {
-                        const int pos = n_live + rank;
-                        lk[pos] = k; lub[pos] = ub; lsum[4 * pos] = b.pr; lsum[4 * pos + 1] = b.pi; lsum[4 * pos + 2] = b.e; lsum[4 * pos + 3] = b.r;
-                    }
-                    const unsigned long long tm = __builtin_amdgcn_ballot_w64(take);
-                    n_live += __builtin_popcountll(tm);
-                    am &= ~tm;
-                    st_fence();
+                e_k = st_wrap(e_k + 64, p.epn); q_k = st_wrap(q_k + 64, p.qn);
                 }
-                if (k_hi >= kE) { flush_live(); done = true; }   // the window is closed: every interval up to kE has been seen
+                // the verdict of this iteration goes into the control slot of the iteration's parity: the slot is rewritten two
+                // iterations later, after a further barrier, so a wavefront that is late reading it can never see the next verdict
+                if (lane == 0) { ctl[2 * (i & 1)] = done ? 1 : 0; ctl[2 * (i & 1) + 1] = s_stop; }
+                const long long tc = now();
+                lds_barrier();   // tile i is summed, step i - 1 is judged
+                if (prof) { const long long td = now(); ct3 += tc - ta - tev; ct4 += tev; ct5 += td - tc; }
+                const int stop = __builtin_amdgcn_readfirstlane(ctl[2 * (i & 1)]);
+                s_stop = __builtin_amdgcn_readfirstlane(ctl[2 * (i & 1) + 1]);
+                if (stop || i >= s_stop) break;
             }
-            slot_s = st_wrap(slot_s + 1, ring_tiles); slot_i = st_wrap(slot_i + 1, ring_tiles);
-            e_new = st_wrap(e_new + 64, p.epn); q_new = st_wrap(q_new + 64, p.qn);
-            e_k = st_wrap(e_k + 64, p.epn); q_k = st_wrap(q_k + 64, p.qn);
-        }
-        // a frame whose last tiles were issued but not consumed cannot exist: tiles are issued only below s_stop, and s_stop
-        // only shrinks to a value above every tile issued so far (need >= s + 3 when the crossing is found in step s)
-        if (d1 >= 0 && !done) flush_live();                   // the capture ended inside the window
-        if (d1 >= 0) best = sc_pick(best, sc_wave_best(mybest));
-        if (lane == 0) {
-            if (best.lag == INT_MAX || d1 < 0) { p.d_hat[f] = -1; if (p.f_delta) p.f_delta[f] = 0.0; if (p.metric) p.metric[f] = 0.f; }
-            else {
-                p.d_hat[f] = best.lag;
-                if (p.f_delta) p.f_delta[f] = atan2(best.pi, best.pr) / (double)L;
-                if (p.metric) p.metric[f] = (float)(best.num / best.den);
+            // ---- close the window: what is left on the list is evaluated lag by lag (the producer is already fetching the next frame)
+            const long long tcl = now();
+            if (d1 >= 0) { flush_live(); best = sc_pick(best, sc_wave_best(mybest)); }
+            const long long tend = now();
+            if (lane == 0) {
+                if (best.lag == INT_MAX || d1 < 0) { p.d_hat[f] = -1; if (p.f_delta) p.f_delta[f] = 0.0; if (p.metric) p.metric[f] = 0.f; }
+                else {
+                    p.d_hat[f] = best.lag;
+                    if (p.f_delta) p.f_delta[f] = atan2(best.pi, best.pr) / (double)L;
+                    if (p.metric) p.metric[f] = (float)(best.num / best.den);
+                }
+                if (prof && p.metric) {   // (the producer left its loop, and wrote its ticks, before this wavefront's last barrier released)
+                    const long long v[8] = {ptk[0], ptk[1], ptk[2], ct3, ct4, ct5, tend - tcl, tend - t_frame};
+                    p.metric[f] = (float)v[(p.debug - 40) & 7];
+                }
             }
         }
-        st_wait_vm<0>();   // nothing of this frame may still be landing when the next frame's tiles are issued
         st_fence();
     }
+    st_wait_vm<0>();
 }
 
 // one tile-aligned streaming pass: L = 160 .. 1280 with 80 | L, 16-byte aligned frames (LDS-DMA), lags that fit 32-bit intervals
@@ -397,19 +499,24 @@ hipError_t run_sc_stream(const ScParams &p, int num_cu, hipStream_t st) {
     StParams q;
     q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride; q.frame_len = p.frame_len; q.n_lags = p.n_lags;
     q.L = p.L; q.W = p.W; q.threshold = p.threshold;
-    q.ring = ((p.L + ST_T - 1) / ST_T + 3) * ST_T;
-    q.epn = (p.W + p.L) / 10 + 72; q.qn = p.W / 10 + 72;
+    const int delay = (p.L % ST_T == 0 && p.L / ST_T <= 2) ? p.L / ST_T : 0;
+    // samples kept for the partner micro-chunk (none when it lives in the producer's registers) + the tile being summed + two in flight
+    q.ring = (delay ? 3 : (p.L + ST_T - 1) / ST_T + 3) * ST_T;
+    q.epn = (p.W + p.L) / 10 + 136; q.qn = p.W / 10 + 136;   // one step of history more than a step needs: producer and consumer overlap
     q.d_hat = p.d_hat; q.f_delta = p.f_delta; q.metric = p.metric;
-    const size_t lds = (size_t)q.ring * sizeof(float2) + (size_t)(q.epn + 2 * q.qn) * sizeof(double) + (size_t)ST_LIVE * (4 * sizeof(double) + 8) + 64;
+    q.debug = kProfile ? tuning_or_default(p.tune).debug_sc : 0;
+    const size_t lds = (size_t)q.ring * sizeof(float2) + (size_t)(q.epn + 2 * q.qn) * sizeof(double) + (size_t)ST_LIVE * (4 * sizeof(double) + 8) + 32 + 32 + 64;   // rings, list, control slots, profile ticks
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
-    if (per_cu > 4) per_cu = 4;   // the kernel is built for one wavefront per SIMD
+    if (per_cu > 4) per_cu = 4;   // two wavefronts per frame, built for two wavefronts per SIMD
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)num_cu * per_cu;
     const Tuning &tu = tuning_or_default(p.tune);
     if (tu.grid_cap > 0 && grid > tu.grid_cap) grid = tu.grid_cap;
     if (grid > p.n_frames) grid = p.n_frames;
-    trace_add(p.trace, "k_sc_stream");
-    hipLaunchKernelGGL(k_sc_stream, dim3((unsigned)grid), dim3(64), lds, st, q);
+    trace_add(p.trace, delay ? "k_sc_stream<regs>" : "k_sc_stream");
+    if (delay == 2) hipLaunchKernelGGL(k_sc_stream<2>, dim3((unsigned)grid), dim3(128), lds, st, q);
+    else if (delay == 1) hipLaunchKernelGGL(k_sc_stream<1>, dim3((unsigned)grid), dim3(128), lds, st, q);
+    else hipLaunchKernelGGL(k_sc_stream<0>, dim3((unsigned)grid), dim3(128), lds, st, q);
     return hipGetLastError();
 }
 
