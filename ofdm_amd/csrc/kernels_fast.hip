@@ -270,12 +270,32 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
     const int wr = swz(8 * t);
 
     const long long n_items = p.frame_list ? (long long)*p.frame_count : p.n_frames;
-    for (long long item = (long long)blockIdx.x * 4 + wave; item < n_items; item += (long long)gridDim.x * 4) {
-        const long long f = p.frame_list ? (long long)p.frame_list[item] : item;
-        const int ns = p.nsym[f];
+    // The per-frame scalars (live symbols, offset, CFO) of the NEXT frame of this wavefront are fetched while the current frame is
+    // received: read where they are used -- symbol count, branch, offset, CFO, one after the other -- they cost three to four
+    // dependent round trips to HBM per frame before the first sample is even requested.
+    const long long istep = (long long)gridDim.x * 4;
+    // (A VGPR zero the compiler cannot fold keeps these wave-uniform loads per-lane loads: as scalar values they would be moved to
+    // SGPRs, and waited for, right where they are issued.)
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));
+    long long f_n = 0; int ns_v = 0, off_v = 0; double fd_v = 0.0;
+    auto fetch_scalars = [&](long long item) {
+        if (item < n_items) {
+            f_n = p.frame_list ? (long long)p.frame_list[item] : item;
+            const long long fi = f_n + vzero;
+            ns_v = p.nsym[fi];
+            off_v = p.offset ? p.offset[fi] : 0;
+            fd_v = p.f_delta ? p.f_delta[fi] : 0.0;
+        }
+    };
+    fetch_scalars((long long)blockIdx.x * 4 + wave);
+    for (long long item = (long long)blockIdx.x * 4 + wave; item < n_items; item += istep) {
+        const long long f = f_n;
+        const int ns = __builtin_amdgcn_readfirstlane(ns_v);
+        const long long off = __builtin_amdgcn_readfirstlane(off_v);
+        const double turns = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(fd_v)), __builtin_amdgcn_readfirstlane(__double2loint(fd_v))) * 0.15915494309189533577;
+        fetch_scalars(item + istep);   // in flight until the next iteration reads them
         if (ns <= 0) { if (p.final_out && lane == 0) p.final_len[f] = 0; continue; } // wave-uniform
-        const long long off = p.offset ? p.offset[f] : 0;
-        const double turns = p.f_delta ? p.f_delta[f] * 0.15915494309189533577 : 0.0;
         const cf st = cfo_phasor(turns, 8);
         int keep = 0; // fused finish: bytes of this frame's output (known once the first group is demodulated)
         const cf *src = p.in + f * p.frame_stride + off;

@@ -104,33 +104,31 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         bo8[q] = carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * 16 + row) * BPS : -1;
     }
 
+    // Per-frame scalars: the three loads of a frame go out together and are waited for once (as wave-uniform scalar values each
+    // would be moved to SGPRs, and waited for, right where it is issued: three dependent round trips to HBM per frame).
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));   // a VGPR zero the compiler cannot fold: keeps the loads per-lane
     auto open_frame = [&](Cur &c, long long f) {
-        while (f < p.n_frames && p.nsym[f] <= 0) {
-            if (fused && tid == 0) p.final_len[f] = 0;   // no sync / short capture: nothing decoded (every skipped frame is visited exactly once: by the issue cursor)
+        for (;;) {
+            c.f = f; c.step = -5; c.rel = 0; c.ns = 0; c.turns = 0.0;
+            if (f >= p.n_frames) return;
+            const long long fi = f + vzero;
+            const int ns_v = p.nsym[fi];
+            const int off_v = p.offset ? p.offset[fi] : 0;
+            const double fd_v = p.f_delta ? p.f_delta[fi] : 0.0;
+            c.ns = __builtin_amdgcn_readfirstlane(ns_v);
+            c.rel = __builtin_amdgcn_readfirstlane(off_v);
+            c.turns = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(fd_v)), __builtin_amdgcn_readfirstlane(__double2loint(fd_v))) * 0.15915494309189533577;
+            if (c.ns > 0) return;
+            if (fused && tid == 0) p.final_len[f] = 0;   // no sync / short capture: nothing decoded (every skipped frame is visited exactly once)
             f += gridDim.x;
         }
-        c.f = f; c.step = -5; c.rel = 0; c.ns = 0; c.turns = 0.0;
-        if (f < p.n_frames) {
-            c.rel = p.offset ? p.offset[f] : 0;
-            c.ns = p.nsym[f];
-            c.turns = p.f_delta ? p.f_delta[f] * 0.15915494309189533577 : 0.0;
-        }
     };
-    auto advance = [&](Cur &c, bool skipping_marks) {
-        if (++c.step >= c.ns) {
-            long long f = c.f + gridDim.x;
-            if (skipping_marks) open_frame(c, f);
-            else { // the consume cursor follows the frames the issue cursor opened: same skip rule, no side effects
-                while (f < p.n_frames && p.nsym[f] <= 0) f += gridDim.x;
-                c.f = f; c.step = -5; c.rel = 0; c.ns = 0; c.turns = 0.0;
-                if (f < p.n_frames) {
-                    c.rel = p.offset ? p.offset[f] : 0;
-                    c.ns = p.nsym[f];
-                    c.turns = p.f_delta ? p.f_delta[f] * 0.15915494309189533577 : 0.0;
-                }
-            }
-        }
-    };
+    // The consume cursor never loads: when it leaves a frame the issue cursor (one item ahead, and a frame has at least six) is
+    // already inside the next live one.
+    Cur ic, cc;
+    auto advance_issue = [&]() { if (++ic.step >= ic.ns) open_frame(ic, ic.f + gridDim.x); };
+    auto advance_consume = [&]() { if (++cc.step >= cc.ns) { cc = ic; cc.step = -5; } };
     // Stage item c into ring slot `slot`: x[j] = frame[rel + chunk S + CP + j] lands at slot[j + ((rel + ...) & 1)].
     // Returns true when the LDS-DMA path was taken (its pieces are then outstanding on this wavefront's VM counter).
     auto issue = [&](const Cur &c, int slot) -> bool {
@@ -158,16 +156,15 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         return false;
     };
 
-    Cur ic, cc;                       // issue and consume cursors
-    open_frame(ic, blockIdx.x);
+    open_frame(ic, blockIdx.x);       // issue and consume cursors start at the workgroup's first live frame
     cc = ic;
     bool dma_cur = false, dma_next = false;   // how the item under the consume cursor / the one after it were staged
     bool have_next = false;
     long long k = 0;                  // items consumed so far: item k lives in slot k % RING
     if (ic.f < p.n_frames) {
         dma_cur = issue(ic, 0);
-        advance(ic, true);
-        if (RING == 3 && ic.f < p.n_frames) { dma_next = issue(ic, 1); have_next = true; advance(ic, true); }
+        advance_issue();
+        if (RING == 3 && ic.f < p.n_frames) { dma_next = issue(ic, 1); have_next = true; advance_issue(); }
     }
     unsigned *pending = nullptr;      // unfused mode: where the symbol image currently in LDS belongs
     cf g[8];                          // first the time-domain sum of the derotated training blocks, then 1 / H
@@ -184,7 +181,7 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         const int slot = (int)(k % RING);
         // ---- the item two ahead goes into the slot item k - 1 has just left
         bool dma_issued = false, issued = false;
-        if (ic.f < p.n_frames) { dma_issued = issue(ic, (int)((k + RING - 1) % RING)); issued = true; advance(ic, true); }
+        if (ic.f < p.n_frames) { dma_issued = issue(ic, (int)((k + RING - 1) % RING)); issued = true; advance_issue(); }
         if (!fused && pending) {      // unfused: the previous symbol's image leaves for HBM, the LDS image is cleared
             for (int i = tid; i < IMG_DW; i += 128) { pending[i] = raw[i]; raw[i] = 0u; }
             pending = nullptr;
@@ -206,7 +203,7 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         }
         // rotate the bookkeeping now: everything below refers to (f, step, slotp) only
         const bool last_of_frame = step == ns - 1;
-        advance(cc, false);
+        advance_consume();
         if (RING == 3) { dma_cur = dma_next; dma_next = dma_issued; have_next = issued; }
         else dma_cur = dma_issued;
         ++k;
