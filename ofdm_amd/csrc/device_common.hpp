@@ -347,6 +347,30 @@ __device__ __forceinline__ void ham_decode_block(const uint8_t *src, uint8_t *ds
     }
 }
 
+// ---- payload dwords fetched ahead of their use
+// A global load under a branch (`if (in_range) v = p[i];`, or `in_range ? p[i] : 0`) is compiled as branch + load +
+// s_waitcnt vmcnt(0) at the join: the "prefetch" is synchronous (found in the round-3 ISA scan; k_sc_stream's evaluations
+// ran 1.7x faster without it).  So the load is issued UNCONDITIONALLY -- from `safe`, any mapped 4-byte aligned address,
+// when bytes by .. by + 3 are not wanted, not wholly inside [0, len) or not 4-byte aligned -- and the verdict is taken
+// where the value is used (paydw_settle), which rebuilds the ragged dword byte by byte.
+__device__ __forceinline__ bool paydw_whole(long long by, long long len, bool want, bool aligned) {
+    return want && aligned && by >= 0 && by + 4 <= len;
+}
+__device__ __forceinline__ unsigned paydw_issue(const uint8_t *base, long long by, long long len, bool want, bool aligned, const void *safe) {
+    const unsigned *src = paydw_whole(by, len, want, aligned) ? reinterpret_cast<const unsigned *>(base + by)
+                                                              : reinterpret_cast<const unsigned *>(safe);
+    return *src;
+}
+__device__ __forceinline__ unsigned paydw_settle(unsigned raw, const uint8_t *base, long long by, long long len, bool want, bool aligned) {
+    if (paydw_whole(by, len, want, aligned)) return raw;
+    unsigned v = 0;
+    if (want) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (by + j >= 0 && by + j < len) v |= (unsigned)base[by + j] << (8 * j);
+    }
+    return v;
+}
+
 // ---- LDS-DMA (global_load_lds) staging helpers
 // Workgroup barrier that does NOT drain the VM counter: the next tile's LDS-DMA stays in flight across it.
 // (__syncthreads() would emit s_waitcnt vmcnt(0) while a global_load_lds is outstanding.)

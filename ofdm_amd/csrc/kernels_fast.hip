@@ -489,9 +489,9 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
     cf *hd = reinterpret_cast<cf *>(smem);                      // [800] the constant header, staged once
     cf *fb = hd + HDR;                                          // [ceil8(n_sym) * 80] data symbols, unnormalised
     const int groups = (p.n_sym + 7) >> 3;
-    unsigned *mxw = reinterpret_cast<unsigned *>(fb + (size_t)groups * 8 * S); // frame maximum (float bits, >= 0)
-    unsigned *sbw = mxw + 4;                                                   // the frame's byte stream, as dwords
-    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
+    unsigned *mxw = reinterpret_cast<unsigned *>(fb + (size_t)groups * 8 * S); // [2] frame maximum (float bits, >= 0), by frame parity
+    unsigned *sbw_all = mxw + 4;                                               // [2][groups * 128 + 8] the frame's byte stream as dwords, by frame parity
+    const int sbw_dw = groups * 128 + 8;
     const int stream_dw = groups * 8 * (SYM_BITS / 8) / 4 + 1;  // dwords the mapper may touch (one dword of slack)
 
     const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x, nwaves = nthr >> 6;
@@ -521,33 +521,55 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
         for (int j = 0; j < 4; ++j) if (b0 + j < len) v |= (unsigned)pay[b0 + j] << (8 * j);
         return v;
     };
+    // The prefetch is issued without a branch and without knowing the frame's length (a load under a branch, or behind the
+    // scalar load of payload_len[f], is a synchronous one): dwords wholly inside the payload ROW (payload_bytes, mapped
+    // whatever the frame's own length) are loaded as they are and cut to the frame's length when they are taken out of
+    // the registers; the ragged last dword of a row whose size is not a multiple of 4 is rebuilt byte by byte there.
+    // payload_len[f] itself travels with them as a per-lane load (a VGPR zero the compiler cannot fold keeps it off the
+    // scalar unit, whose loads are waited for at the next LDS wait).
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));
+    const bool row0 = aligned && 4LL * tid + 4 <= p.payload_bytes, row1 = aligned && 4LL * (tid + nthr) + 4 <= p.payload_bytes;
+    auto issue = [&](long long fr, unsigned &d0, unsigned &d1, int &ln) {
+        const long long fc = fr < p.n_frames ? fr : p.n_frames - 1; // past the batch: any mapped row, the values are never used
+        const uint8_t *row = p.payload + fc * p.payload_stride;
+        d0 = *reinterpret_cast<const unsigned *>(row0 ? row + 4 * tid : reinterpret_cast<const uint8_t *>(p.tw));
+        d1 = *reinterpret_cast<const unsigned *>(row1 ? row + 4 * (tid + nthr) : reinterpret_cast<const uint8_t *>(p.tw));
+        ln = p.payload_len ? p.payload_len[fc + vzero] : p.payload_bytes;
+    };
+    auto settle = [&](unsigned raw, bool whole, const uint8_t *pay, long long len, int i) -> unsigned {
+        const long long keep = len - 4LL * i;                    // payload bytes from this dword on
+        if (whole) return keep >= 4 ? raw : (keep <= 0 ? 0u : raw & ((1u << (8 * (int)keep)) - 1u));
+        return pay_dword(pay, len, i);
+    };
+    // Per frame: [barrier] map + IFFT out of this frame's byte stream -> next frame's bytes out of the prefetch registers
+    // into the OTHER stream buffer, the frame after next's loads issued -> [barrier] normalise + store.  The prefetched
+    // loads are waited for BEFORE this frame's stores are issued: loads and stores share the in-order VM counter, and a
+    // wait placed after the stores (the round-2 layout took the registers at the top of the next frame) drains them all.
+    auto fill = [&](unsigned *sbw, long long fr, unsigned d0, unsigned d1, long long len) {
+        const uint8_t *pay = p.payload + fr * p.payload_stride;
+        if (tid < 4) sbw[tid] = tid < 2 ? (unsigned)((unsigned long long)len >> (32 * tid)) : 0u;
+        if (tid + 4 < stream_dw) sbw[4 + tid] = settle(d0, row0, pay, len, tid);
+        if (tid + nthr + 4 < stream_dw) sbw[4 + tid + nthr] = settle(d1, row1, pay, len, tid + nthr);
+        for (int i = tid + 2 * nthr; i + 4 < stream_dw; i += nthr) sbw[4 + i] = pay_dword(pay, len, i); // long payloads
+    };
     long long f = blockIdx.x;
     unsigned pre0 = 0, pre1 = 0;
+    int pre_len = 0;
+    long long len = 0;
+    int cur = 0;
     if (f < p.n_frames) {
-        const long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
-        const uint8_t *pay = p.payload + f * p.payload_stride;
-        pre0 = pay_dword(pay, len, tid); pre1 = pay_dword(pay, len, tid + nthr);
+        issue(f, pre0, pre1, pre_len);
+        len = __builtin_amdgcn_readfirstlane(pre_len);
+        fill(sbw_all, f, pre0, pre1, len);
+        issue(f + gridDim.x, pre0, pre1, pre_len);
     }
-    for (; f < p.n_frames; f += gridDim.x) {
-        lds_only_barrier(); // the previous frame has left LDS (and the header is staged)
+    if (tid < 2) mxw[tid] = 0u;
+    for (; f < p.n_frames; f += gridDim.x, cur ^= 1) {
+        lds_only_barrier(); // this frame's byte stream is complete; the previous frame has left LDS (and the header is staged)
         const long long t0 = kProfile && p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        const long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
-        const uint8_t *pay = p.payload + f * p.payload_stride;
-        if (tid < 4) sbw[tid] = tid < 2 ? (unsigned)((unsigned long long)len >> (32 * tid)) : 0u;
-        if (tid + 4 < stream_dw) sbw[4 + tid] = pre0;
-        if (tid + nthr + 4 < stream_dw) sbw[4 + tid + nthr] = pre1;
-        for (int i = tid + 2 * nthr; i + 4 < stream_dw; i += nthr) sbw[4 + i] = pay_dword(pay, len, i); // long payloads
-        if (tid == 0) *mxw = 0u;
-        {   // next frame's payload: in flight while this frame is built and written
-            const long long fn = f + gridDim.x;
-            if (fn < p.n_frames) {
-                const long long ln = p.payload_len ? p.payload_len[fn] : p.payload_bytes;
-                const uint8_t *pn = p.payload + fn * p.payload_stride;
-                pre0 = pay_dword(pn, ln, tid); pre1 = pay_dword(pn, ln, tid + nthr);
-            }
-        }
-        lds_only_barrier();
-        const long long t1 = kProfile && p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw_all + cur * sbw_dw);
+        long long t1 = 0;
         const int npoints = (int)(((16 + len) * 8 + BPS - 1) / BPS); // points that carry stream bits; the rest are 0
         float lmax = 0.f;
         for (int g = wave; g < groups; g += nwaves) {
@@ -592,10 +614,19 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
         }
 #pragma unroll
         for (int sh = 32; sh >= 1; sh >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, sh, 64));
-        if (lane == 0) atomicMax(mxw, __float_as_uint(lmax)); // non-negative floats order like their bit patterns
+        if (lane == 0) atomicMax(&mxw[cur], __float_as_uint(lmax)); // non-negative floats order like their bit patterns
+        if (kProfile && p.debug) t1 = (long long)__builtin_amdgcn_s_memtime();
+        long long len_next = 0;
+        if (f + gridDim.x < p.n_frames) { // workgroup-uniform
+            len_next = __builtin_amdgcn_readfirstlane(pre_len);
+            fill(sbw_all + (cur ^ 1) * sbw_dw, f + gridDim.x, pre0, pre1, len_next);
+        }
+        if (tid == 0) mxw[cur ^ 1] = 0u; // last read in the previous frame's store phase, which every thread left before this frame's first barrier
+        issue(f + 2LL * gridDim.x, pre0, pre1, pre_len);
         lds_only_barrier();
         const long long t2 = kProfile && p.debug ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        const float inv = 1.0f / fmaxf(p.header_max, __uint_as_float(*mxw)); // one divide per thread, then multiplies (<= 1 ulp)
+        const float inv = 1.0f / fmaxf(p.header_max, __uint_as_float(mxw[cur])); // one divide per thread, then multiplies (<= 1 ulp)
+        len = len_next;
         // stream [header | data] out: header and data are contiguous in LDS, two samples per 16-byte store
         const int total2 = (HDR + p.n_sym * S) >> 1;
         float4 *dst = reinterpret_cast<float4 *>(p.out + f * p.out_stride);
@@ -613,7 +644,7 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
             __syncthreads();
             if (tid == 0) {
                 const long long t3 = (long long)__builtin_amdgcn_s_memtime();
-                dst[0] = make_float4((float)(t1 - t0), (float)(t2 - t1), (float)(t3 - t2), 0.f);
+                dst[0] = make_float4((float)(t1 - t0), (float)(t2 - t1), (float)(t3 - t2), 0.f); // map + IFFT, next frame's bytes, stores
             }
         }
     }
@@ -639,7 +670,7 @@ hipError_t run_txframe64(const SymParams &sp, const float2 *header, float header
     const Tuning &tu = tuning_or_default(sp.tune);
     p.debug = kProfile ? tu.debug_tx : 0;
     const int groups = (n_sym + 7) / 8;
-    const size_t lds = (size_t)(800 + groups * 8 * 80) * sizeof(float2) + 16 + (size_t)groups * 8 * 64 + 32; // header + frame + max + byte stream
+    const size_t lds = (size_t)(800 + groups * 8 * 80) * sizeof(float2) + 16 + 2 * ((size_t)groups * 8 * 64 + 32); // header + frame + max + two byte streams
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
     const int waves_per_cu = tu.tx_waves > 0 ? tu.tx_waves : 16; // tuning knob (measured best: 16)
     long long wave_cap = waves_per_cu / (groups < 4 ? groups : 4); // wavefronts per CU
@@ -728,17 +759,23 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     // divisions per symbol this replaces were a third of the loop's instruction stream (408 of 1214, all scalar)
     long long fn = blockIdx.x / p.syms_per_frame;
     int kn = (int)(blockIdx.x - fn * p.syms_per_frame);
-    auto fetch = [&](long long sg, cf *dst) {
-        if (sg < p.total) {
-            const long long off = FRAME && p.offset ? p.offset[fn] : 0;
-            const long long n0 = off + (long long)(p.first_symbol + kn) * S + CP + col;
-            const cf *src = p.in + fn * p.frame_stride + n0;
-            const long long room = FRAME ? p.frame_len - n0 : 0;
+    // Loads are issued without a branch (a load under `if (in range)` is followed by s_waitcnt vmcnt(0) at the join, i.e. is
+    // synchronous): out-of-range elements read the twiddle table instead and are zeroed when they leave the prefetch registers.
+    // room = samples from this lane's first one to the end of the capture (FRAME), 0 past the batch.
+    auto fetch = [&](long long sg, cf *dst, int &room) {
+        const bool in = sg < p.total;
+        const long long fr = in ? fn : 0;
+        const long long off = FRAME && p.offset ? p.offset[fr] : 0;
+        const long long n0 = off + (long long)(p.first_symbol + kn) * S + CP + col;
+        const cf *src = p.in + fr * p.frame_stride + n0;
+        long long rm = FRAME ? p.frame_len - n0 : (long long)N;
+        rm = in ? rm : 0;
+        room = (int)(rm < 0 ? 0 : (rm > N ? N : rm));
 #pragma unroll
-            for (int m = 0; m < 8; ++m) dst[m] = (!FRAME || 64 * (t + 8 * m) < room) ? src[64 * (t + 8 * m)] : make_float2(0.f, 0.f);
-        } else {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) dst[m] = make_float2(0.f, 0.f);
+        for (int m = 0; m < 8; ++m) {
+            const int i = 64 * (t + 8 * m);
+            const cf *a = FRAME ? (i < room ? src + i : p.tw + i) : (in ? src : p.tw) + i; // p.tw: N mapped entries
+            dst[m] = *a;
         }
     };
     // The image of symbol j is stored to HBM at the top of iteration j + 1, right after that iteration's samples have
@@ -749,7 +786,8 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     };
     for (int i = tid; i < IMG_DW; i += 512) img[i] = 0u;
     cf pre[8];
-    fetch(blockIdx.x, pre);
+    int room_pre = 0;
+    fetch(blockIdx.x, pre, room_pre);
     unsigned *pending = nullptr; // where the image currently in LDS belongs
 
     for (long long sg = blockIdx.x; sg < p.total; sg += gridDim.x) {
@@ -759,8 +797,8 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
         if (kn >= p.syms_per_frame) { kn -= p.syms_per_frame; ++fn; }
         cf v[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = pre[m];
-        fetch(sg + gridDim.x, pre);
+        for (int m = 0; m < 8; ++m) v[m] = (!FRAME || 64 * (t + 8 * m) < room_pre) ? pre[m] : make_float2(0.f, 0.f);
+        fetch(sg + gridDim.x, pre, room_pre);
         if (pending) flush(pending);
         bool live = true;
         if (FRAME) {
@@ -960,26 +998,26 @@ __global__ __launch_bounds__(512, 4) void k_tx4096(Tx4096Params p) {
     const int nd = GUARD ? 48 * 64 : N;
     const int sym_bytes = nd * p.bps / 8;   // <= 4096, multiple of 4 (checked by the launcher)
     const bool aligned = (reinterpret_cast<uintptr_t>(p.bytes) & 3) == 0;
-    auto dword = [&](long long by) -> unsigned { // stream bytes by .. by + 3, zero past the end
-        if (aligned && by + 4 <= p.n_bytes) return *reinterpret_cast<const unsigned *>(p.bytes + by);
-        unsigned v = 0;
-        for (int j = 0; j < 4; ++j) if (by + j < p.n_bytes) v |= (unsigned)p.bytes[by + j] << (8 * j);
-        return v;
-    };
+    // stream bytes of symbol sg, two dwords per thread: issued without a branch (paydw_issue), settled where they are used
+    const bool want0 = 4 * tid < sym_bytes, want1 = 4 * (tid + 512) < sym_bytes;
     auto fetch = [&](long long sg, unsigned &d0, unsigned &d1) {
-        d0 = d1 = 0u;
-        if (sg >= p.n_sym) return;
         const long long base = sg * sym_bytes;
-        if (4 * tid < sym_bytes) d0 = dword(base + 4 * tid);
-        if (4 * (tid + 512) < sym_bytes) d1 = dword(base + 4 * (tid + 512));
+        const bool in = sg < p.n_sym;
+        d0 = paydw_issue(p.bytes, base + 4 * tid, p.n_bytes, in && want0, aligned, p.tw);
+        d1 = paydw_issue(p.bytes, base + 4 * (tid + 512), p.n_bytes, in && want1, aligned, p.tw);
+    };
+    auto settle = [&](long long sg, unsigned d0, unsigned d1) {
+        const long long base = sg * sym_bytes;
+        const bool in = sg < p.n_sym;
+        sbw[tid] = paydw_settle(d0, p.bytes, base + 4 * tid, p.n_bytes, in && want0, aligned);
+        sbw[tid + 512] = paydw_settle(d1, p.bytes, base + 4 * (tid + 512), p.n_bytes, in && want1, aligned);
     };
     // The bytes of symbol j+1 are taken out of the prefetch registers (and symbol j+2's loads issued) BEFORE symbol j's
     // samples are stored: loads and stores share the in-order VM counter, so a wait for prefetched loads placed after the
     // stores would wait for the stores as well.
     unsigned d0, d1;
     fetch(blockIdx.x, d0, d1);
-    sbw[tid] = d0;
-    sbw[tid + 512] = d1;
+    settle(blockIdx.x, d0, d1);
     if (tid < 2) sbw[1024 + tid] = 0u; // slack for the two-byte window
     fetch((long long)blockIdx.x + gridDim.x, d0, d1);
     __syncthreads();
@@ -1017,8 +1055,7 @@ __global__ __launch_bounds__(512, 4) void k_tx4096(Tx4096Params p) {
         for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
         bfly8<true>(v);
         // v[q] = N x[col + 64 (t + 8 q)]; prefix_block: out = [x[N - CP .. N), x[0 .. N)]
-        sbw[tid] = d0;               // next symbol's bytes (every wavefront left the mapping stage two barriers ago)
-        sbw[tid + 512] = d1;
+        settle(sg + gridDim.x, d0, d1); // next symbol's bytes (every wavefront left the mapping stage two barriers ago)
         fetch(sg + 2 * (long long)gridDim.x, d0, d1);
         // transpose once more through T ([n >> 6][n & 63], the conflict-free layout of the first transpose) so that every
         // store is a full 16 bytes per lane and 1 KiB per wavefront

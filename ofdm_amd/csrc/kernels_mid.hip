@@ -176,28 +176,24 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
         const long long sg0 = (long long)blockIdx.x * G + g;
         fn = sg0 / p.syms_per_frame; kn = (int)(sg0 - fn * p.syms_per_frame);
     }
-    auto fetch = [&](long long sg, cf *dst) {
-        if (sg < p.total) {
-            const long long off = FRAME && p.offset ? p.offset[fn] : 0;
-            const long long n0 = off + (long long)(p.first_symbol + kn) * S + CP + colA; // first sample of this lane, inside the frame
-            const cf *src = p.in + fn * p.frame_stride + n0;
-            const long long room = FRAME ? p.frame_len - n0 : 0;                          // samples from n0 to the end of the capture
-            if (R >= 8) {
+    // Loads are issued without a branch (a load under `if (in range)` is followed by s_waitcnt vmcnt(0) at the join, i.e. is
+    // synchronous): out-of-range elements read the twiddle table instead and are zeroed when they leave the prefetch registers.
+    // room = samples from this lane's first one to the end of the capture (FRAME), 0 past the batch.
+    auto elem = [&](int e) -> int { return R >= 8 ? 64 * (u + Q * e) : 64 * (e % R) + LPS * (e / R); }; // stage-A input e, relative to the lane's first sample
+    auto fetch = [&](long long sg, cf *dst, int &room) {
+        const bool in = sg < p.total;
+        const long long fr = in ? fn : 0;
+        const long long off = FRAME && p.offset ? p.offset[fr] : 0;
+        const long long n0 = off + (long long)(p.first_symbol + kn) * S + CP + colA; // first sample of this lane, inside the frame
+        const cf *src = p.in + fr * p.frame_stride + n0;
+        long long rm = FRAME ? p.frame_len - n0 : (long long)N;
+        rm = in ? rm : 0;
+        room = (int)(rm < 0 ? 0 : (rm > N ? N : rm));
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int i = 64 * (u + Q * m);
-                    dst[m] = (!FRAME || i < room) ? src[i] : make_float2(0.f, 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int i = 64 * (e % R) + LPS * (e / R);
-                    dst[e] = (!FRAME || i < room) ? src[i] : make_float2(0.f, 0.f);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) dst[m] = make_float2(0.f, 0.f);
+        for (int e = 0; e < 8; ++e) {
+            const int i = elem(e);
+            const cf *a = FRAME ? (i < room ? src + i : p.tw + i) : (in ? src : p.tw) + i; // p.tw: N mapped entries
+            dst[e] = *a;
         }
     };
     // The image of step j leaves for HBM at the top of step j + 1, right after that step's samples have been taken out of
@@ -208,7 +204,8 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
     };
     for (int i = l; i < IMG_DW; i += LPS) myimg[i] = 0u;
     cf pre[8];
-    fetch((long long)blockIdx.x * G + g, pre);
+    int room_pre = 0;
+    fetch((long long)blockIdx.x * G + g, pre, room_pre);
     unsigned *pending = nullptr;
     const long long stride = (long long)gridDim.x * G;
 
@@ -219,8 +216,8 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
         if (kn >= p.syms_per_frame) { kn -= p.syms_per_frame; ++fn; }
         cf v[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = pre[m];
-        fetch(sg + stride, pre);
+        for (int m = 0; m < 8; ++m) v[m] = (!FRAME || elem(m) < room_pre) ? pre[m] : make_float2(0.f, 0.f);
+        fetch(sg + stride, pre, room_pre);
         if (pending) flush(pending);
         bool live = sg < p.total;
         if (FRAME) {
@@ -410,24 +407,24 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
     }
     const int sym_bytes = ND * p.bps / 8;           // <= 64 R, a multiple of 4 (checked by the launcher)
     const bool aligned = (reinterpret_cast<uintptr_t>(p.bytes) & 3) == 0;
-    auto dword = [&](long long by) -> unsigned {    // stream bytes by .. by + 3, zero past the end
-        if (aligned && by + 4 <= p.n_bytes) return *reinterpret_cast<const unsigned *>(p.bytes + by);
-        unsigned v = 0;
-        for (int j = 0; j < 4; ++j) if (by + j < p.n_bytes) v |= (unsigned)p.bytes[by + j] << (8 * j);
-        return v;
-    };
+    // stream bytes of symbol sg, two dwords per lane: issued without a branch (paydw_issue), settled where they are used
+    const bool want0 = 4 * l < sym_bytes, want1 = 4 * (l + LPS) < sym_bytes;
     auto fetch = [&](long long sg, unsigned &d0, unsigned &d1) {
-        d0 = d1 = 0u;
-        if (sg >= p.n_sym) return;
         const long long base = sg * sym_bytes;
-        if (4 * l < sym_bytes) d0 = dword(base + 4 * l);
-        if (4 * (l + LPS) < sym_bytes) d1 = dword(base + 4 * (l + LPS));
+        const bool in = sg < p.n_sym;
+        d0 = paydw_issue(p.bytes, base + 4 * l, p.n_bytes, in && want0, aligned, p.tw);
+        d1 = paydw_issue(p.bytes, base + 4 * (l + LPS), p.n_bytes, in && want1, aligned, p.tw);
+    };
+    auto settle = [&](long long sg, unsigned d0, unsigned d1) {
+        const long long base = sg * sym_bytes;
+        const bool in = sg < p.n_sym;
+        sbw[l] = paydw_settle(d0, p.bytes, base + 4 * l, p.n_bytes, in && want0, aligned);
+        sbw[l + LPS] = paydw_settle(d1, p.bytes, base + 4 * (l + LPS), p.n_bytes, in && want1, aligned);
     };
     const long long stride = (long long)gridDim.x * G;
     unsigned d0, d1;
     fetch((long long)blockIdx.x * G + g, d0, d1);
-    sbw[l] = d0;
-    sbw[l + LPS] = d1;
+    settle((long long)blockIdx.x * G + g, d0, d1);
     if (l < 2) sbw[2 * LPS + l] = 0u;
     fetch((long long)blockIdx.x * G + g + stride, d0, d1);
     __syncthreads();
@@ -461,8 +458,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
             Tsym[slot * TS + col] = (R < 8 && e % R == 0) ? v[e] : cmul(v[e], z[e]);
         }
         symbol_sync<LPS>(); // T complete; every lane of the symbol is past the mapping stage
-        sbw[l] = d0;        // next symbol's bytes
-        sbw[l + LPS] = d1;
+        settle(sg + stride, d0, d1); // next symbol's bytes
         fetch(sg + 2 * stride, d0, d1);
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = T[rs * TS + t + 8 * m];
