@@ -347,6 +347,14 @@ __device__ __forceinline__ void ham_decode_block(const uint8_t *src, uint8_t *ds
     }
 }
 
+// One 8-byte load of a complex sample through a pointer that came out of a select: as a struct of two floats the compiler
+// splits such a load into two global_load_dword (it no longer sees that the halves are adjacent).
+__device__ __forceinline__ cf ld_cf(const cf *a) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v r = *reinterpret_cast<const f2v *>(a);
+    return make_float2(r.x, r.y);
+}
+
 // ---- payload dwords fetched ahead of their use
 // A global load under a branch (`if (in_range) v = p[i];`, or `in_range ? p[i] : 0`) is compiled as branch + load +
 // s_waitcnt vmcnt(0) at the join: the "prefetch" is synchronous (found in the round-3 ISA scan; k_sc_stream's evaluations

@@ -19,6 +19,7 @@
 // Roofline: HBM -- 640 algorithmic bytes read per symbol (512 actually fetched) + packed bytes written.
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include <type_traits>
 #include <mutex>
 #include <stdlib.h>
 
@@ -257,16 +258,23 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
     cf *buf = slab_all + wave * SLAB + s * 72;
     unsigned *img = img_all + wave * REGION_DW;
 
-    cf w[7];
+    // Lane constants that k_demod64 keeps in registers live in LDS here (22 VGPRs): with a second set of sample registers for the
+    // next group's prefetch the kernel would otherwise spill at three waves per SIMD, and a spill reload waits for vmcnt(0),
+    // i.e. for the prefetch.  twl[m] = W64^m (the stage twiddles W64^(r t) and the one-point-per-lane transform's twiddles: as
+    // global loads their six loop-invariant 64-bit addresses are hoisted by the compiler and one of them spills);
+    // bofftab[m * 64 + lane] = bit offset of bin t + 8 m, -1 = not data.
+    __shared__ cf twl[64];
+    __shared__ int bofftab[8 * 64];
+    if (threadIdx.x < 64) twl[threadIdx.x] = p.tw[threadIdx.x];
+    if (wave == 0) {
 #pragma unroll
-    for (int r = 1; r < 8; ++r) w[r - 1] = p.tw[r * t];
-    int bitoff[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int c = t + 8 * m;
-        const int q = GUARD ? data_classes_below64(c) : c;
-        bitoff[m] = (carrier_class64(c, GUARD) == 0) ? (s * ND + q) * BPS : -1;
+        for (int m = 0; m < 8; ++m) {
+            const int c = t + 8 * m;
+            const int q = GUARD ? data_classes_below64(c) : c;
+            bofftab[m * 64 + lane] = (carrier_class64(c, GUARD) == 0) ? (s * ND + q) * BPS : -1;
+        }
     }
+    __syncthreads();
     const int wr = swz(8 * t);
 
     const long long n_items = p.frame_list ? (long long)*p.frame_count : p.n_frames;
@@ -301,22 +309,56 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
         const cf *src = p.in + f * p.frame_stride + off;
         const long long avail = p.frame_len - off; // samples of the trimmed frame
 
+        auto frame_body = [&](auto cut_tag) {
+        constexpr bool CUT = decltype(cut_tag)::value;
         // estimate_channel (receiver.rs:212-229) on the 5 training blocks (chunks 5..9): H = mean_b FFT(block_b) / training
         // = FFT(mean_b block_b) / training.  Lane n sums sample n of the 5 derotated blocks, the wavefront transforms the 64
         // sums with one point per lane (lane_fft64), lane l then holds bin bitrev6(l): ONE transform per frame instead of a
         // whole 8-symbol group iteration.  1/H goes through the wave's LDS slab into the (t + 8 m) register layout.
+        // The frame's round trips to HBM overlap instead of following one another: the first data group's samples are requested
+        // right behind the training blocks (before the channel estimate is computed), every further group while the one before it
+        // is transformed.
+        // Every load is issued unconditionally, in straight-line code, from an address that is always mapped: loads under
+        // exec-mask branches (or on one side of a branch that joins before their first use) make the compiler wait for
+        // vmcnt(0) where the FIRST of them is used, i.e. for the prefetch as well.  Lanes of symbols past the frame's count
+        // transform the frame's first samples: their image words are never stored.  CUT (a capture that ends inside the frame,
+        // wave-uniform per frame) is a second instance of the whole body: there elements at or beyond frame_len read the frame's
+        // first samples too and are zeroed where the registers are taken (zmask, bit m).
+        const cf *safe = p.in + f * p.frame_stride + t;
+        auto issue_group = [&](int k0, cf *v, unsigned &zmask) {
+            const int count = ns - k0 < 8 ? ns - k0 : 8;
+            const int n0 = (10 + k0 + s) * S + CP + t; // sample id of this lane's first point
+            const cf *base = s < count ? src + n0 : safe;
+            zmask = 0u;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const bool pad = CUT && s < count && (n0 + 8 * m) >= avail;
+                v[m] = ld_cf(pad ? safe : base + 8 * m);
+                if (CUT) zmask |= pad ? 1u << m : 0u;
+            }
+        };
         cf *ginv = ginv_all + wave * 64;
+        cf v[8];
+        unsigned zm = 0u;
         {
-            cf tws[6];
+            cf tws[6]; // twiddles of the one-point-per-lane transform
+            int lq = lane;
+            asm volatile("" : "+v"(lq)); // per frame: keeps the six LDS addresses out of the loop-invariant registers (they spilled)
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 const int h = 32 >> q;
-                tws[q] = (lane & h) ? p.tw[(lane & (h - 1)) << q] : make_float2(1.f, 0.f);
+                const cf x = twl[(lq & (h - 1)) << q];
+                tws[q] = (lane & h) ? x : make_float2(1.f, 0.f);
             }
+            const int bin = bitrev6(lane);
+            const cf invt = p.inv_training[bin]; // requested with the training blocks (read after the transform it is one more dependent round trip)
             const int nb = 5 * S + CP + lane;
             cf xb[5];
 #pragma unroll
-            for (int b = 0; b < 5; ++b) xb[b] = (nb + S * b) < avail ? src[nb + S * b] : make_float2(0.f, 0.f);
+            for (int b = 0; b < 5; ++b) xb[b] = ld_cf((!CUT || (nb + S * b) < avail) ? src + nb + S * b : safe);
+            issue_group(0, v, zm);
+#pragma unroll
+            for (int b = 0; b < 5; ++b) if (CUT && (nb + S * b) >= avail) xb[b] = make_float2(0.f, 0.f);
             cf acc;
             if (p.f_delta) { // sum_b x_b e^{-j phi (nb + 80 b)}: Horner in the 80-sample step, then this lane's phasor
                 const cf s80 = cfo_phasor(turns, S), q0 = cfo_phasor(turns, nb);
@@ -327,8 +369,7 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
                 acc = cmul(acc, q0);
             } else acc = cadd(cadd(cadd(xb[4], xb[3]), cadd(xb[2], xb[1])), xb[0]);
             acc = lane_fft64(acc, lane, tws);
-            const int bin = bitrev6(lane);
-            cf h = cmul(acc, p.inv_training[bin]);                   // 64-entry table, L2/L1 resident
+            cf h = cmul(acc, invt);
             h = make_float2(h.x * 0.2f, h.y * 0.2f);
             if (p.hk) p.hk[f * 64 + bin] = h;
             const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
@@ -339,24 +380,17 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
         for (int k0 = 0; k0 < ns; k0 += 8) { // data symbols, 8 at a time (chunks 10..)
             const int count = ns - k0 < 8 ? ns - k0 : 8;
             const int n0 = (10 + k0 + s) * S + CP + t; // sample id of this lane's first point
-            cf v[8];
-            const bool all_inside = (long long)(10 + k0 + count) * S <= avail; // wave-uniform: no tail padding in this group
-            if (s < count) {
-                if (all_inside) {
+            cf vn[8];
+            unsigned zn = 0u;
+            issue_group(k0 + 8 < ns ? k0 + 8 : k0, vn, zn); // the next group (past the last one: this group again, never used)
+            if (CUT && zm) {
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) v[m] = src[n0 + 8 * m];
-                } else {
+                for (int m = 0; m < 8; ++m) if ((zm >> m) & 1u) v[m] = make_float2(0.f, 0.f);
+            }
+            if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50)
+                cf ph = cfo_phasor(turns, n0);
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) v[m] = (n0 + 8 * m) < avail ? src[n0 + 8 * m] : make_float2(0.f, 0.f);
-                }
-                if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50)
-                    cf ph = cfo_phasor(turns, n0);
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
+                for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
             }
             bfly8<false>(v);
 #pragma unroll
@@ -364,7 +398,7 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
 #pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twl[r * t]);
             bfly8<false>(v);
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], ginv[t + 8 * m]); // equalise (receiver.rs:68-70)
@@ -382,15 +416,21 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
             for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                if (bitoff[m] >= 0) {
+                const int bo = bofftab[m * 64 + lane];
+                if (bo >= 0) {
                     const unsigned idx = demap_point(v[m], BPS);
-                    const int wd = bitoff[m] >> 5, sh = bitoff[m] & 31;
+                    const int wd = bo >> 5, sh = bo & 31;
                     atomicOr(&img[wd], idx << sh);
                     if (BPS > 1 && (32 % BPS) != 0) {
                         if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
                     }
                 }
             }
+            // the next group's samples leave the prefetch registers BEFORE this group's bytes are stored: loads and stores share the
+            // in-order VM counter, so a wait for the loads placed behind the stores would wait for the stores as well
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = vn[m];
+            zm = zn;
             const int ndw = count * (SYM_BYTES / 4);
             if (p.final_out) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the image is complete
@@ -413,6 +453,8 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
                 for (int i = lane; i < ndw; i += 64) dst[i] = img[i];
             }
         }
+        };
+        if ((long long)(10 + ns) * S <= avail) frame_body(std::false_type{}); else frame_body(std::true_type{}); // wave-uniform
     }
 }
 
