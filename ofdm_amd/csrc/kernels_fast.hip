@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], g[m]);
         }
+        cf rot = make_float2(1.f, 0.f);
         if (GUARD) {
             // decode_block (src/receiver.rs:106-145): mean of the 4 pilot angles, rotate data points by -phase
             // pilots sit at bins 6, 25, 39, 58 = lanes t = 6 (m 0), 1 (m 3), 7 (m 4), 2 (m 7); the other lanes
@@ -135,9 +136,7 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
             // mean angle in TURNS (sum of the four atan2pi values / 8), then the hardware sine / cosine, which take turns:
             // max abs error 1.3e-7 over [-pi, pi] on gfx950 (tools/trig_probe.cpp; sincospif: 5e-8) for 2 instructions instead of ~35
             const float turns = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.125f;
-            const cf rot = make_float2(__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns));
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
+            rot = make_float2(__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns)); // applied inside the demapper (demap_point_rot)
         }
         if (kProfile && p.debug == 2) { // profiling aid: everything but the packing and the stores
             float acc = 0.f;
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
             // no per-lane test, no exec-mask juggling for half of the fields
             const bool all_data = !GUARD || m == 1 || m == 2 || m == 5 || m == 6;
             if (all_data || fs[m] != 0xFFFFFFFFu) {
-                const unsigned idx = demap_point(v[m], BPS);
+                const unsigned idx = GUARD ? demap_point_rot(v[m], rot, BPS) : demap_point(v[m], BPS);
                 const lds_u32_ptr wd = (lds_u32_ptr)(unsigned long)(fa[m] + img_off);
                 __hip_atomic_fetch_or(wd, idx << fs[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)
@@ -402,6 +401,7 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
             bfly8<false>(v);
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], ginv[t + 8 * m]); // equalise (receiver.rs:68-70)
+            cf rot = make_float2(1.f, 0.f);
             if (GUARD) {
                 cf pv = make_float2(1.f, 0.f);
                 pv = (t == 6) ? v[0] : pv;
@@ -409,16 +409,14 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
                 pv = (t == 7) ? v[4] : pv;
                 pv = (t == 2) ? v[7] : pv;
                 const float trn = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.125f; // mean pilot angle in turns -> hardware sin / cos
-                const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
-#pragma unroll
-                for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
+                rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn)); // applied inside the demapper
             }
             for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int bo = bofftab[m * 64 + lane];
                 if (bo >= 0) {
-                    const unsigned idx = demap_point(v[m], BPS);
+                    const unsigned idx = GUARD ? demap_point_rot(v[m], rot, BPS) : demap_point(v[m], BPS);
                     const int wd = bo >> 5, sh = bo & 31;
                     atomicOr(&img[wd], idx << sh);
                     if (BPS > 1 && (32 % BPS) != 0) {
@@ -892,6 +890,7 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
                 v[q] = make_float2(e.x * rn, e.y * rn);
             }
         }
+        cf rot = make_float2(1.f, 0.f);
         if (GUARD) { // decode_block (src/receiver.rs:106-145): mean angle of the 4 x 64 pilots, rotate by -phase
             // pilot classes 6, 25, 39, 58 = (t, q) = (6, 0), (1, 3), (7, 4), (2, 7); other lanes feed (1, 0) -> angle 0
             cf pv = make_float2(1.f, 0.f);
@@ -908,9 +907,7 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
 #pragma unroll
             for (int i = 0; i < 8; ++i) tot += red[i];
             const float trn = tot * (0.5f / 256.0f); // mean of the 256 pilot angles, in turns -> hardware sin / cos
-            const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
+            rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn)); // applied inside the demapper
         }
         // demodulate (src/receiver.rs:147-190) and pack LSB-first (src/utils.rs:30-36)
         if (BPS == 8 || BPS == 4) {
@@ -924,7 +921,7 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
                 // non-writing lanes store to a spare dword behind the image (exec-mask branches cost more than the stores)
                 const bool all_data = !GUARD || q == 1 || q == 2 || q == 5 || q == 6;
                 const bool data = live && (all_data || boff[q] >= 0); // a dead symbol writes nothing into the image
-                unsigned val = demap_point(v[q], BPS) << (BPS * (s & (32 / BPS - 1)));
+                unsigned val = (GUARD ? demap_point_rot(v[q], rot, BPS) : demap_point(v[q], BPS)) << (BPS * (s & (32 / BPS - 1)));
                 val = data ? val : 0u;
                 val |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x128, 0xF, 0xF, true);          // row_ror:8   : s ^ 1
                 val |= (unsigned)__builtin_amdgcn_ds_swizzle((int)val, 0x401F);                               // xor 16      : s ^ 2
@@ -935,7 +932,7 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
 #pragma unroll
             for (int q = 0; q < 8; ++q) { // OR every field into the image; a dead symbol (k >= nsym_frame[f]) must leave it clear:
                 if (live && boff[q] >= 0) { // nothing flushes the image after such a step, and demap_point(0) != 0 for BPS >= 2
-                    const unsigned idx = demap_point(v[q], BPS);
+                    const unsigned idx = GUARD ? demap_point_rot(v[q], rot, BPS) : demap_point(v[q], BPS);
                     const int wd = boff[q] >> 5, sh = boff[q] & 31;
                     atomicOr(&img[wd], idx << sh);
                     if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
                 v[q] = make_float2(e.x * rn, e.y * rn);
             }
         }
+        cf rot = make_float2(1.f, 0.f);
         if (GUARD) { // decode_block (src/receiver.rs:106-145): mean angle of the 4 R pilots, rotate by -phase
             // pilot classes 6, 25, 39, 58 = (t, q) = (6, 0), (1, 3), (7, 4), (2, 7); other lanes feed (1, 0) -> angle 0
             cf pv = make_float2(1.f, 0.f);
@@ -288,9 +289,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
                 for (int i = 0; i < LPS / 64; ++i) a += red[g * (LPS / 64) + i];
             }
             const float trn = a * (0.5f / (4.0f * R)); // mean of the 4 R pilot angles, in turns -> hardware sin / cos
-            const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
+            rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn)); // applied inside the demapper
         }
         // demodulate (src/receiver.rs:147-190) and pack LSB-first (src/utils.rs:30-36): OR every field into the image
         // A dead symbol (past the batch, or k >= nsym_frame[f]) must leave the image untouched: nothing flushes (and clears) it
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (live && boff[q] >= 0) {
-                const unsigned idx = demap_point(v[q], BPS);
+                const unsigned idx = GUARD ? demap_point_rot(v[q], rot, BPS) : demap_point(v[q], BPS);
                 const int wd = boff[q] >> 5, sh = boff[q] & 31;
                 atomicOr(&myimg[wd], idx << sh);
                 if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)

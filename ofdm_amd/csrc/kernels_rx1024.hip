@@ -270,6 +270,7 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], g[q]); // equalise (receiver.rs:68-70)
+        cf rot = make_float2(1.f, 0.f);
         if (GUARD) { // decode_block (receiver.rs:106-145): mean angle of the 4 x 16 pilots, rotate by -phase
             cf pv = make_float2(1.f, 0.f);
             pv = (t == 6) ? v[0] : pv;
@@ -282,16 +283,14 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
             if (lane == 0) red[wave] = a;
             lds_barrier();            // B4
             const float trn = (red[0] + red[1]) * (0.5f / 64.0f); // mean of the 64 pilot angles, in turns
-            const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = cmul(v[q], rot);
+            rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn)); // applied inside the demapper
         }
         unsigned *img = fused ? raw + step * IMG_DW : raw;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { // demodulate + LSB-first packing: OR every field into the image
             const int bo = bo8[q];
             if (bo >= 0) {
-                const unsigned idx = demap_point(v[q], BPS);
+                const unsigned idx = GUARD ? demap_point_rot(v[q], rot, BPS) : demap_point(v[q], BPS);
                 const int wd = bo >> 5, shf = bo & 31;
                 atomicOr(&img[wd], idx << shf);
                 if (BPS > 1 && (32 % BPS) != 0) {

@@ -812,6 +812,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                 bfly8<false>(v);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], ginv[t + 8 * m]); // equalise (receiver.rs:68-70); 1/H read at use: 16 fewer live registers
+                cf rot = make_float2(1.f, 0.f);
                 if (GUARD) { // decode_block (receiver.rs:106-145): mean of the 4 pilot angles, rotate by -phase
                     cf pv = make_float2(1.f, 0.f);
                     pv = (t == 6) ? v[0] : pv;
@@ -819,16 +820,14 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                     pv = (t == 7) ? v[4] : pv;
                     pv = (t == 2) ? v[7] : pv;
                     const float trn = sum8_lanes(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.125f; // mean pilot angle in turns
-                    const cf rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn));
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], rot);
+                    rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn)); // applied inside the demapper
                 }
                 unsigned *img = obuf + k0 * (SYM_BYTES / 4);      // this group's part of the frame's packed image
                 for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     if (bitoff[m] >= 0 && act) {
-                        const unsigned idx = demap_point(v[m], BPS);
+                        const unsigned idx = GUARD ? demap_point_rot(v[m], rot, BPS) : demap_point(v[m], BPS);
                         const int wd = bitoff[m] >> 5, shf = bitoff[m] & 31;
                         atomicOr(&img[wd], idx << shf);
                         if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)
