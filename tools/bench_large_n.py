@@ -155,7 +155,7 @@ def cfg4(n_frames=65536, total_frames=10_000_000, cpu=True, snr_db=40.0, grp=Non
                      "roofline": {"bound": "hbm", "achieved": chain_bytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": chain_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": chain_bytes,
                                   "per": "GPU (slowest rank)",
-                                  "kernels": "Schmidl-Cox (L = 1280) + k_rx_prepare + k_rxframe1024<6,true> + k_rx_finish (Hamming)"}}
+                                  "kernels": "k_sc_stream<2> (L = 1280, stops when the peak window has closed) + k_rx_prepare + k_rxframe1024<6,true> (Hamming decode fused); see dispatch"}}
         if lags == 0:
             full = r
     if cpu and rank == 0:
