@@ -23,6 +23,9 @@ struct Tuning {
     long long grid_cap = 0;        // > 0: caps every persistent grid (test hook: many steps per workgroup on a small batch)
     int tx_waves = 16;             // k_txframe64: wavefronts per CU
     int sc_wg_per_cu = 7;          // k_sc_cf: persistent workgroups per CU
+    int sc_first_lags = 384;       // k_sc_cf, searches of >= twice as many lags: the lags the first launch looks at (0 = one launch over every lag).
+                                   // 384 = a crossing up to lag 143 with its whole window of W = 240 lags: a packet that starts within ~64 samples of its slot (config 3);
+                                   // later packets are found by the second launch.  Measured per 262 144 config-3 frames: 0 -> 1.81 ms, 320 -> 2.28, 384 -> 1.47, 448 .. 640 -> 1.52
     int demod64_wg_per_cu = 0;     // k_demod64: persistent workgroups per CU (0 = from the occupancy API)
     int demod64_burst = 16;        // k_demod64: groups per store burst (16 / 8 / 4; 1 = no bursts)
     int demod64_narrow_stores = 0; // k_demod64: 4-byte instead of 16-byte image stores

@@ -293,6 +293,13 @@ struct ScFastParams {
     int32_t *slow_list; // frames the filter could not settle
     int32_t *slow_count;
     struct ScExact *exact; // exact sums at the chosen lag, per frame
+    // Two-phase search (run_sc_fast): the first launch looks at the first n_lags lags only and puts every frame whose result those
+    // lags do not DETERMINE -- no crossing among them, or a peak window that reaches beyond them -- on the redo list; the second
+    // launch runs the whole search for the frames of that list (frame_list / frame_count).
+    int defer;                    // 1: undetermined frames go to redo_list instead of getting a result
+    int32_t *redo_list, *redo_count;
+    const int32_t *frame_list;    // optional: only these frames (count on the device)
+    const int32_t *frame_count;
     ScRxParams rx;
 };
 
@@ -470,17 +477,23 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
     if (RX && tid < 64) twl[tid] = p.rx.tw[tid];
     cf itrn = make_float2(0.f, 0.f);  // 1 / training[bitrev6(lane)]: the bin this lane holds after the lane FFT
     if (RX) itrn = p.rx.inv_training[bitrev6(lane)];
-    long long f = blockIdx.x;
+    auto to_redo = [&](long long fr) { p.redo_list[atomicAdd(p.redo_count, 1)] = (int32_t)fr; };
+    const bool listed = !RX && p.frame_list != nullptr;
+    const long long n_items = listed ? (long long)*p.frame_count : p.n_frames;
+    auto frame_of = [&](long long item) -> long long { return listed ? (long long)p.frame_list[item] : item; };
+    long long item = blockIdx.x;
     const long long fstep = gridDim.x;
-    if (f < p.n_frames) stage(f);
+    if (item < n_items) stage(frame_of(item));
     int it = blockIdx.x;
 
-    for (; f < p.n_frames; f += fstep, ++it) {
+    for (; item < n_items; item += fstep, ++it) {
+        const long long f = frame_of(item);
         const long long t0 = (dbg >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of the CURRENT frame have landed
         lds_barrier();                                   // B0: ... and everyone else's
         const long long t1 = (dbg >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        const bool more = f + fstep < p.n_frames;
+        const bool more = item + fstep < n_items;
+        const long long f_next = more ? frame_of(item + fstep) : 0;
         // ---- phase 1 (f32): chunk totals of q and e; exclusive prefixes WITHIN each virtual wavefront (64 chunks) go to
         //      LDS together with the wavefront totals.  A prefix difference that crosses into the next virtual wavefront
         //      just adds the first one's total, so no second scan across wavefronts (and no barrier for it) is needed.
@@ -509,7 +522,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
         }
         lds_barrier(); // B3: chunk prefixes, energies and wavefront totals visible
         const long long t2 = t1, t3 = (dbg >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        if (!RX && dbg == 2) { lds_barrier(); if (more) stage(f + fstep); continue; }
+        if (!RX && dbg == 2) { lds_barrier(); if (more) stage(f_next); continue; }
         float etot = 0.f; // frame energy: bounds every prefix (error margin of the coarse bound)
 #pragma unroll
         for (int wv = 0; wv < VW; ++wv) etot += wtot[wv * 4 + 2];
@@ -559,12 +572,13 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                 if (RX) {
                     p.rx.status[f] = -2; p.rx.offset[f] = 0; p.rx.out_len[f] = 0; p.rx.f_delta[f] = 0.0;
                     if (p.rx.metric) p.rx.metric[f] = 0.f;
-                } else p.d_hat[f] = -1;
+                } else if (p.defer) to_redo(f);   // nothing in the first lags: the whole search has to look
+                else p.d_hat[f] = -1;
             }
-            if (more) stage(f + fstep);   // every wave is done with the raw samples (phase 1 ended before B3)
+            if (more) stage(f_next);   // every wave is done with the raw samples (phase 1 ended before B3)
             continue;
         }
-        if (!RX && dbg == 3) { lds_barrier(); if (more) stage(f + fstep); continue; }
+        if (!RX && dbg == 3) { lds_barrier(); if (more) stage(f_next); continue; }
 
         // ---- fine pass: one wavefront, the 32 chunks (320 lags) from the first flagged one; lane 2k slides forward from
         //      chunk boundary k over lags +0..+4, lane 2k+1 slides BACKWARD from boundary k+1 over lags +9..+5
@@ -572,7 +586,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
             const int hh = lane & 1;
             const float sgn = hh ? -1.f : 1.f;
             long long u0 = (!RX && dbg >= 15) ? (long long)__builtin_amdgcn_s_memtime() : 0, u1 = 0, u2 = 0;
-            int res_d = -1;          // wave-uniform outcome: lag >= 0, -1 no packet, -2 slow list, -3 debug exit
+            int res_d = -1;          // wave-uniform outcome: lag >= 0, -1 no packet, -2 slow list, -3 debug exit, -4 redo list
             Cand best = Cand{0.0, 1.0, 1.0, 0.0, INT_MAX};
             for (;;) {
                 const int c = gs + (lane >> 1), m0 = c * C;
@@ -640,6 +654,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                 const int c_hi = hi_m ? __builtin_amdgcn_readlane(hi, __ffsll((long long)hi_m) - 1) : INT_MAX;
                 if (c_lo != c_hi) { res_d = -2; break; }                  // ambiguous crossing: redo in f64
                 const int d1 = c_lo;
+                if (!RX && p.defer && d1 + W > n - 1) { res_d = -4; break; } // the peak window reaches beyond the first lags: whole search
                 const int dend = d1 + W < n - 1 ? d1 + W : n - 1;        // last lag of the peak window
                 if (dend >= (gs + 32) * C) { gs = d1 / C; continue; }    // window not covered: restart at the crossing's chunk
                 // window maximum over the trusted lags, then the candidates within 2 EPS of it (+ the untrusted ones)
@@ -680,6 +695,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
             if (!RX) {
                 if (lane == 0 && res_d != -3) {
                     if (res_d == -2) to_slow(f);
+                    else if (p.defer && (res_d == -4 || res_d == -1)) to_redo(f); // undetermined by the first lags
                     else {
                         p.d_hat[f] = res_d;
                         if (res_d >= 0) p.exact[f] = ScExact{best.pr, best.pi, best.num, best.den};
@@ -729,7 +745,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                 const long long dt[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4};
                 p.d_hat[f] = (int32_t)dt[dbg - 10 < 5 ? dbg - 10 : 4];
             }
-            if (more) stage(f + fstep);
+            if (more) stage(f_next);
             continue;
         }
         const long long t5 = (dbg >= 20) ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -839,7 +855,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
         }
         lds_barrier(); // B6: the packed image is complete; nobody reads the raw samples any more
         const long long t6 = (dbg >= 20) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        if (more) stage(f + fstep);                                  // next frame's DMA flies while this one is finished
+        if (more) stage(f_next);                                  // next frame's DMA flies while this one is finished
         for (int i = nstaged + tid; i < ns + L; i += WG) raw[i] = make_float2(0.f, 0.f); // a tail symbol's slab may have spilled into the zero pad
         if (st_f == 0) { // ---- length header, truncate (receiver.rs:85-95) [, Hamming(7,4)], bytes to their final place
             const unsigned lo0 = obuf[0], lo1 = obuf[1], hi0 = obuf[2], hi1 = obuf[3]; // bincode fixint little-endian u128
@@ -900,7 +916,7 @@ bool sc_rx_fused_ok(const ScParams &p, const ScRxFused &rx) {
     return rx.out && rx.out_len && rx.status && rx.offset && rx.f_delta && rx.tw && rx.inv_training && rx.atan_tab;
 }
 size_t sc_fast_workspace_bytes(long long n_frames, int /*W*/) {
-    return (size_t)n_frames * (sizeof(ScExact) + sizeof(int32_t)) + 64; // exact sums + slow list (+ its counter)
+    return (size_t)n_frames * (sizeof(ScExact) + 2 * sizeof(int32_t)) + 128; // exact sums + slow list + redo list (+ their counters)
 }
 
 template <int BPS> static void launch_sc_rx(bool guard, dim3 grid, size_t lds, hipStream_t st, const ScFastParams &q) {
@@ -918,11 +934,14 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     ScExact *exact = reinterpret_cast<ScExact *>(workspace);
     int32_t *slow_count = reinterpret_cast<int32_t *>(exact + p.n_frames);
     int32_t *slow_list = slow_count + 4;
+    int32_t *redo_count = slow_list + p.n_frames;
+    int32_t *redo_list = redo_count + 4;
     if (slow_list_out) *slow_list_out = slow_list;
     if (slow_count_out) *slow_count_out = slow_count;
     hipError_t e = hipMemsetAsync(slow_count, 0, 16, st);
     if (e != hipSuccess) return e;
     ScFastParams q;
+    q.defer = 0; q.redo_list = redo_list; q.redo_count = redo_count; q.frame_list = nullptr; q.frame_count = nullptr;
     q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride;
     const long long tile_n = (long long)nch * 10;
     long long stage = p.frame_len < tile_n ? p.frame_len : tile_n;
@@ -963,7 +982,32 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         default: return hipErrorInvalidValue;
         }
     } else if (nch == 256) {
-        trace_add(p.trace, "k_sc_cf<256>");
+        // Two-phase search.  The detector is threshold-then-peak: once the first crossing d1 is known nothing after lag d1 + W can
+        // change the answer, so the first `first` lags DETERMINE the result of every frame whose crossing and whole peak window lie
+        // among them (a packet near the start of its slot: the usual case).  Launch 1 searches those lags only -- it stages and sums
+        // first + W + L samples instead of the slot -- and lists the frames they do not determine (no crossing there, or a window
+        // that reaches beyond); launch 2 is the whole search over that list.  Results are those of the whole search on every frame.
+        const int first = tu.sc_first_lags;
+        bool two_phase = first > 0 && p.n_lags >= 2LL * first && (long long)128 * 10 - p.W - p.L >= first && first > p.W + 1;
+        if (two_phase) {
+            if ((e = hipMemsetAsync(redo_count, 0, 16, st)) != hipSuccess) return e;
+            ScFastParams q1 = q;
+            q1.n_lags = first; q1.defer = 1;
+            long long stage1 = (first + p.W + p.L + 10 + 1) & ~1LL;
+            if (stage1 > p.frame_len) stage1 = p.frame_len & ~1LL;
+            q1.n16 = (int)(stage1 / 2);
+            const size_t lds1 = sc_cf_lds_bytes(p.L, 128, stage1, false);
+            long long pc = (long long)(160 * 1024) / (long long)lds1;
+            if (pc > 10) pc = 10;
+            long long g1 = (long long)num_cu * pc;
+            if (g1 > gcap) g1 = gcap;
+            if (g1 > p.n_frames) g1 = p.n_frames;
+            trace_add(p.trace, "k_sc_cf<128,first>");
+            hipLaunchKernelGGL((k_sc_cf<128, 1, 5, 0, false>), dim3((unsigned)g1), dim3(128), lds1, st, q1);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            q.frame_list = redo_list; q.frame_count = redo_count;
+            trace_add(p.trace, "k_sc_cf<256,list>");
+        } else trace_add(p.trace, "k_sc_cf<256>");
         hipLaunchKernelGGL((k_sc_cf<256, 2, 4, 0, false>), dim3((unsigned)grid), dim3(128), lds, st, q); // <= 7 x 2 waves per CU
     } else { // 128-chunk tile (bounded searches): 128 threads, one chunk each, up to 10 workgroups per CU (measured best)
         per_cu = (long long)(160 * 1024) / (long long)lds;

@@ -412,6 +412,7 @@ const TuneKey kTuneKeys[] = {
     {"no_rx1024_finish", &Tuning::no_rx1024_finish, false},
     {"tx_waves", &Tuning::tx_waves, false},
     {"sc_wg_per_cu", &Tuning::sc_wg_per_cu, false},
+    {"sc_first_lags", &Tuning::sc_first_lags, false},
     {"demod64_wg_per_cu", &Tuning::demod64_wg_per_cu, false},
     {"demod64_burst", &Tuning::demod64_burst, false},
     {"demod64_narrow_stores", &Tuning::demod64_narrow_stores, false},

@@ -397,6 +397,53 @@ def test_sc_correlate_batch(api, orc):
         assert host(d2)[f] == orc.sc_sync(wide(caps[f][:2000]), 80, 3, 256, 0.5)[0]
 
 
+def test_sc_correlate_two_launch_search_equals_the_whole_search(api, orc):
+    """N = 64 searches over many lags run as two launches (kernels_sync.hip, run_sc_fast): the first looks at the first
+    `sc_first_lags` lags only and lists every frame those lags do not DETERMINE (no crossing among them, or a peak window that
+    reaches beyond them), the second is the whole search over that list.  Packets whose crossing lies well inside, just inside
+    (window cut by the boundary), on and beyond the first lags, noise-only and empty slots, on a capped grid (the list is walked
+    by a persistent grid): every result bit-identical to the single-launch search, and to the oracle's."""
+    rng = np.random.default_rng(77)
+    span, firsts = 2400, (384, 300, 900)
+    payload = bytes(rng.integers(0, 256, 200, dtype=np.uint8))
+    delays = [1, 40, 64, 100, 110, 118, 119, 120, 121, 130, 200, 206, 207, 208, 209, 250, 359, 360, 361, 700, 810, 811, 812, 1500, 1790, 2000]
+    caps = []
+    for d in delays:   # the crossing sits at about d + 80 + 9 - W .. : delays chosen around first - W - 89 for each `first`
+        c, _ = make_capture(orc, rng, orc.QAM64, True, payload, span, d, (rng.random() * 1.9 - 0.95) * np.pi / 80)
+        caps.append(c)
+    caps.append(np.zeros(span, np.complex64))
+    caps.append(fc32(0.05 * (rng.standard_normal(span) + 1j * rng.standard_normal(span))))
+    caps = np.stack(caps * 3)   # 81 frames: more than the capped grid
+    want = [orc.sc_sync(wide(c), 80, 3, 0, 0.5) for c in caps[: len(delays) + 2]]
+    ref = None
+    for first in (0,) + firsts:
+        ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning={"sc_first_lags": first, "grid_cap": 5})
+        d_hat, f_delta, metric = (host(t) for t in ctx.sc_correlate(dev(ctx, caps)))
+        disp = ctx.last_dispatch()
+        assert ("k_sc_cf<128,first>+k_sc_cf<256,list>" in disp) == (first > 0), disp
+        if ref is None:
+            ref = (d_hat, f_delta, metric)
+            for f, (wd, _, wm, wfd) in enumerate(want):
+                assert d_hat[f] == wd, f"frame {f}"
+                if wd >= 0:
+                    assert abs(f_delta[f] - wfd) <= 1e-9 and abs(metric[f] - wm) <= 1e-6
+            assert (d_hat[: len(delays) - 1] >= 0).all() and d_hat[len(delays)] == -1 and d_hat[len(delays) + 1] == -1
+        else:
+            assert (d_hat == ref[0]).all() and (f_delta == ref[1]).all() and (metric == ref[2]).all(), f"first = {first}"
+    # the decode chain takes the same path
+    res = []
+    for first in (0, 384):
+        ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning={"sc_first_lags": first})
+        r = ctx.decode_batch(dev(ctx, caps), max_symbols=8)
+        assert ("k_sc_cf<128,first>+k_sc_cf<256,list>" in ctx.last_dispatch()) == (first > 0), ctx.last_dispatch()
+        res.append({k: host(v) for k, v in r.items()})
+    for k in ("status", "offset", "len", "f_delta"):
+        assert (res[0][k] == res[1][k]).all(), k
+    for f in range(caps.shape[0]):   # rows are defined up to the frame's length only
+        assert (res[0]["bytes"][f, : res[0]["len"][f]] == res[1]["bytes"][f, : res[1]["len"][f]]).all(), f
+    assert (res[0]["status"][:20] == 0).all()
+
+
 def test_sc_correlate_untrusted_f32_filter(api, orc):
     # A strong burst ahead of the frame makes the prefix energy >> window energy, so the fast kernel's f32 filter must
     # not be trusted there: those frames are redone by the all-f64 kernel (device-side slow list).  Results still exact.
