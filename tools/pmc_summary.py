@@ -11,4 +11,4 @@ for path in sys.argv[1:]:
             acc[name.split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in sorted(acc.items()):
     for c, vals in sorted(d.items()):
-        print(f"{k}\t{c}\tcalls={len(vals)}\tmean={sum(vals)/len(vals):.1f}")
+        print(f"{k}\t{c}\tcalls={len(vals)}\tmean={sum(vals)/len(vals):.1f}\tmax={max(vals):.1f}")

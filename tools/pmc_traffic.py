@@ -6,10 +6,11 @@ FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE reports half 
 import json, sys
 
 tsv, log, rnd = sys.argv[1:4]
-cnt = {}
+cnt, cmax = {}, {}
 for line in open(tsv):
-    name, ctr, calls, mean = line.rstrip("\n").split("\t")
+    name, ctr, calls, mean, mx = line.rstrip("\n").split("\t")
     cnt[(name.replace("void ", ""), ctr)] = float(mean.split("=")[1])
+    cmax[(name.replace("void ", ""), ctr)] = float(mx.split("=")[1])
 info = next(json.loads(l) for l in open(log) if l.startswith("{"))
 
 
@@ -28,6 +29,11 @@ wf = info["fft_bytes_each_way"] / (fw * 1024.0)      # write factor (about 1)
 
 def rd(kernel): return kib(kernel, "FETCH_SIZE") * 1024.0 * rf
 def wr(kernel): return kib(kernel, "WRITE_SIZE") * 1024.0 * wf
+def rd_max(kernel):   # the largest call (a kernel that also runs over near-empty frame lists)
+    hits = [v for (n, c), v in cmax.items() if c == "FETCH_SIZE" and n.startswith(kernel)]
+    if len(hits) != 1:
+        raise SystemExit(f"{kernel}/FETCH_SIZE: {len(hits)} matches")
+    return hits[0] * 1024.0 * rf
 
 
 n = info["frames_cfg2_cfg3"]; n4 = info["frames_cfg4"]; n5 = info["symbols_cfg5"]
@@ -46,15 +52,17 @@ out = {
                   "algorithmic_read_bytes_per_frame": 10240, "algorithmic_write_bytes_per_frame": 576,
                   "note": "16 symbols x 512 B: the 128-byte cyclic prefix of every 640-byte symbol is never fetched"},
     "cfg3": {"frames": n, "capture_bytes_per_frame": cap3,
-             "staged_k_sc_cf_read_bytes_per_frame": round(rd("ofdm::k_sc_cf<256, 2, 4, 0, false>") / n, 1),
+             "every_lag_k_sc_cf_256_read_bytes_per_frame": round(rd_max("ofdm::k_sc_cf<256, 2, 4, 0, false>") / n, 1),
+             "staged_first_lags_k_sc_cf_128_read_bytes_per_frame": round(rd("ofdm::k_sc_cf<128, 1, 5, 0, false>") / n, 1),
              "staged_k_rxframe64_read_bytes_per_frame": round(rd("ofdm::k_rxframe64<6, true>") / n, 1),
              "staged_k_rxframe64_needed_bytes_per_frame": 21 * 512,
              "one_pass_k_sc_cf_read_bytes_per_frame": round(rd("ofdm::k_sc_cf<256, 2, 3, 6, true>") / n, 1),
              "one_pass_write_bytes_per_frame": round(wr("ofdm::k_sc_cf<256, 2, 3, 6, true>") / n, 1),
              "k_txframe64_read_bytes_per_frame": round(rd("ofdm::k_txframe64<6, true>") / n, 1),
              "k_txframe64_write_bytes_per_frame": round(wr("ofdm::k_txframe64<6, true>") / n, 1),
-             "note": "k_rxframe64 loads 8 B per lane at arbitrary sample offsets; FETCH_SIZE under-reports that pattern (it reads below the "
-                     "10752 B the kernel needs), so the staged chain is claimed at its lower bound 17408 + 10752 B per frame"},
+             "note": "the product's search reads the first 384 + W + L samples of a slot (k_sc_cf<128>) and the whole slot only for frames those "
+                     "lags do not determine; k_rxframe64 loads 8 B per lane at arbitrary sample offsets and FETCH_SIZE under-reports that "
+                     "pattern (it reads below the 10752 B the kernel needs), so the staged chain is claimed at first-lags bytes + 10752 B per frame"},
     "cfg4": {"frames": n4, "capture_bytes_per_frame": cap4, "search": "every lag",
              "k_sc_stream_read_bytes_per_frame": round(rd("ofdm::k_sc_stream<2>") / n4, 1),
              "k_rxframe1024_read_bytes_per_frame": round(rd("ofdm::k_rxframe1024<6, true>") / n4, 1),
