@@ -787,12 +787,25 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     cf z[8];                                      // W4096^(b c), c = t + 8 q
 #pragma unroll
     for (int q = 0; q < 8; ++q) z[q] = p.tw[col * (t + 8 * q)];
-    int boff[8];                                  // bit offset of bin c + 64 d (d = t + 8 q) in the image, -1 = not a data bin
+    // bit offset of bin c + 64 d (d = t + 8 q) in the image, -1 = not a data bin.  Stream mode keeps the eight of them in registers;
+    // frame mode (offsets, CFO phasors, the zero-fill masks of the branch-free fetch on top) spilled 8-17 registers at 128 VGPRs, so
+    // there the offset is rebuilt from a 64-entry LDS table of its column-independent part (a spill reload waits for the prefetch)
+    int boff_r[8];
+    int *btab = reinterpret_cast<int *>(red + 16); // [64] (FRAME only; red + 8 is the spare dword img[1024 + 8] of the packing below)
+    if (FRAME) {
+        if (tid < 64) { const int d = (tid & 7) + 8 * (tid >> 3); btab[tid] = carrier_class64(d, GUARD) == 0 ? (GUARD ? data_classes_below64(d) : d) * 64 * BPS : -1; }
+        __syncthreads();
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int d = t + 8 * q;
-        boff[q] = carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * 64 + col) * BPS : -1;
+        boff_r[q] = FRAME ? 0 : (carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * 64 + col) * BPS : -1);
     }
+    auto boff = [&](int q) -> int {
+        if (!FRAME) return boff_r[q];
+        const int b0 = btab[8 * q + t];
+        return b0 < 0 ? -1 : b0 + col * BPS;
+    };
     constexpr int nbytes = ND * BPS / 8;
 
     // (frame, symbol) of the symbol one step ahead (the prefetch); advanced by the host's per-step increments -- the two 64-bit
@@ -920,20 +933,22 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
                 // branch-free: rows q in {1, 2, 5, 6} hold data bins in every lane; elsewhere non-data lanes contribute 0 and
                 // non-writing lanes store to a spare dword behind the image (exec-mask branches cost more than the stores)
                 const bool all_data = !GUARD || q == 1 || q == 2 || q == 5 || q == 6;
-                const bool data = live && (all_data || boff[q] >= 0); // a dead symbol writes nothing into the image
+                const int bo = boff(q);
+                const bool data = live && (all_data || bo >= 0); // a dead symbol writes nothing into the image
                 unsigned val = (GUARD ? demap_point_rot(v[q], rot, BPS) : demap_point(v[q], BPS)) << (BPS * (s & (32 / BPS - 1)));
                 val = data ? val : 0u;
                 val |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x128, 0xF, 0xF, true);          // row_ror:8   : s ^ 1
                 val |= (unsigned)__builtin_amdgcn_ds_swizzle((int)val, 0x401F);                               // xor 16      : s ^ 2
                 if (BPS == 4) val |= (unsigned)__shfl_xor((int)val, 32, 64);                                  // s ^ 4
-                img[(data && (s & (32 / BPS - 1)) == 0) ? (boff[q] >> 5) : 1024 + 8] = val;
+                img[(data && (s & (32 / BPS - 1)) == 0) ? (bo >> 5) : 1024 + 8] = val;
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) { // OR every field into the image; a dead symbol (k >= nsym_frame[f]) must leave it clear:
-                if (live && boff[q] >= 0) { // nothing flushes the image after such a step, and demap_point(0) != 0 for BPS >= 2
+                const int bo = boff(q);
+                if (live && bo >= 0) { // nothing flushes the image after such a step, and demap_point(0) != 0 for BPS >= 2
                     const unsigned idx = GUARD ? demap_point_rot(v[q], rot, BPS) : demap_point(v[q], BPS);
-                    const int wd = boff[q] >> 5, sh = boff[q] & 31;
+                    const int wd = bo >> 5, sh = bo & 31;
                     atomicOr(&img[wd], idx << sh);
                     if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)
                         if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
@@ -962,7 +977,7 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.bps = sp.bps; p.guard = sp.guard;
     p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym_frame = sp.nsym_frame; p.frame_len = sp.frame_len;
     if (p.total <= 0) return hipSuccess;
-    const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64;
+    const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64 + 256; // slabs, T, image, pilot sums + spare dword, frame-mode offset table
     long long grid = (long long)num_cu * 2;
     { const long long cap = tuning_or_default(sp.tune).grid_cap; if (cap > 0 && cap < grid) grid = cap; } // test hook, as kernels_mid.hip
     if (grid > p.total) grid = p.total;

@@ -130,7 +130,8 @@ struct MidRxParams {
 };
 
 template <int R, int BPS, bool GUARD, bool FRAME>
-__global__ __launch_bounds__(256, Mid<R>::OCC_RX) void k_demod_mid(MidRxParams p) {
+__global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod_mid(MidRxParams p) { // frame mode carries offsets, CFO phasors and the
+    // zero-fill masks of its branch-free fetch: at the stream kernel's occupancy it spills 4-16 registers, and a spill reload waits for the prefetch
     typedef Mid<R> M;
     constexpr int N = M::N, S = M::S, CP = M::CP, LPS = M::LPS, G = M::G, Q = M::Q, TS = M::TS;
     constexpr int ND = GUARD ? 48 * R : N;
@@ -322,7 +323,7 @@ template <int R, int BPS, bool GUARD> hipError_t launch_demod_mid(const MidRxPar
     MidRxParams p = p0;
     constexpr int G = Mid<R>::G;
     const long long steps = (p.total + G - 1) / G;
-    const long long grid = mid_grid(steps, num_cu, Mid<R>::OCC_RX, cap);
+    const long long grid = mid_grid(steps, num_cu, Mid<R>::OCC_RX - (frame ? 1 : 0), cap);
     const long long adv = grid * G;
     p.step_f = adv / p.syms_per_frame;
     p.step_k = (int)(adv - p.step_f * p.syms_per_frame);
