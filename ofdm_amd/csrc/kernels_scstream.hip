@@ -1,4 +1,4 @@
-// kernels_scstream.hip -- k_sc_stream: Schmidl-Cox timing for periods L = 160 .. 1280 (N = 128 .. 1024) in ONE streaming pass
+// kernels_scstream.hip -- k_sc_stream: Schmidl-Cox timing for periods L = 160 .. 5120 (N = 128 .. 4096) in ONE streaming pass
 // that stops as soon as the decision is determined.
 //
 // The detector is threshold-then-peak (oracle: orc_sc_sync): d1 = first lag with M >= threshold,
@@ -487,10 +487,20 @@ __global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
     st_wait_vm<0>();
 }
 
-// one tile-aligned streaming pass: L = 160 .. 1280 with 80 | L, 16-byte aligned frames (LDS-DMA), lags that fit 32-bit intervals
+// LDS of one frame's workgroup: sample ring (the partner micro-chunk lives in registers when L is one or two tiles), prefix rings,
+// live list, control slots, profile ticks
+static size_t sc_stream_lds(int L, int W) {
+    const int delay = (L % ST_T == 0 && L / ST_T <= 2) ? L / ST_T : 0;
+    const int ring = (delay ? 3 : (L + ST_T - 1) / ST_T + 3) * ST_T;
+    const int epn = (W + L) / 10 + 136, qn = W / 10 + 136;
+    return (size_t)ring * sizeof(float2) + (size_t)(epn + 2 * qn) * sizeof(double) + (size_t)ST_LIVE * (4 * sizeof(double) + 8) + 32 + 32 + 64;
+}
+// one tile-aligned streaming pass: L = 160 .. 5120 (N = 128 .. 4096) with 80 | L, 16-byte aligned frames (LDS-DMA), lags that fit
+// 32-bit intervals, rings that fit one CU's LDS (N = 4096: 100 KB, one frame per CU)
 bool sc_stream_ok(const ScParams &p) {
-    if (p.mode != 0 || p.L % 80 != 0 || p.L < 160 || p.L > 1280 || p.W % p.L != 0 || p.W / p.L > 3) return false;
+    if (p.mode != 0 || p.L % 80 != 0 || p.L < 160 || p.L > 5120 || p.W % p.L != 0 || p.W / p.L > 3) return false;
     if ((reinterpret_cast<uintptr_t>(p.in) & 15) != 0 || (p.frame_stride & 1) != 0) return false;
+    if (sc_stream_lds(p.L, p.W) > 150 * 1024) return false;
     return p.n_lags > 0 && p.n_lags + p.W + p.L < (1LL << 30);
 }
 
@@ -505,7 +515,13 @@ hipError_t run_sc_stream(const ScParams &p, int num_cu, hipStream_t st) {
     q.epn = (p.W + p.L) / 10 + 136; q.qn = p.W / 10 + 136;   // one step of history more than a step needs: producer and consumer overlap
     q.d_hat = p.d_hat; q.f_delta = p.f_delta; q.metric = p.metric;
     q.debug = kProfile ? tuning_or_default(p.tune).debug_sc : 0;
-    const size_t lds = (size_t)q.ring * sizeof(float2) + (size_t)(q.epn + 2 * q.qn) * sizeof(double) + (size_t)ST_LIVE * (4 * sizeof(double) + 8) + 32 + 32 + 64;   // rings, list, control slots, profile ticks
+    const size_t lds = sc_stream_lds(p.L, p.W);
+    if (lds > 48 * 1024) { // > 64 KB of dynamic LDS needs the attribute; per device, so set on every such call
+        const void *fn = delay == 2 ? reinterpret_cast<const void *>(k_sc_stream<2>) : delay == 1 ? reinterpret_cast<const void *>(k_sc_stream<1>)
+                                                                                                  : reinterpret_cast<const void *>(k_sc_stream<0>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
     if (per_cu > 4) per_cu = 4;   // two wavefronts per frame, built for two wavefronts per SIMD
     if (per_cu < 1) per_cu = 1;

@@ -834,7 +834,7 @@ def test_long_period_fine_tiles_agree(api):
 
 
 @pytest.mark.parametrize("reps", [3, 1, 2])
-@pytest.mark.parametrize("n", [128, 256, 512, 1024])
+@pytest.mark.parametrize("n", [128, 256, 512, 1024, 2048, 4096])
 def test_sc_stream_detector_against_the_oracle(api, orc, n, reps):
     """k_sc_stream (kernels_scstream.hip): the one-pass, early-exit Schmidl-Cox detector for L = 160 .. 1280, against the oracle's
     exhaustive search (orc_sc_sync) -- timing index bit-exact, CFO to 1e-9, metric to 1e-6 -- on a 2-wavefront grid (many frames per
@@ -890,15 +890,17 @@ def test_sc_stream_detector_against_the_oracle(api, orc, n, reps):
         assert ctx.last_dispatch().startswith("k_sc_stream") or W + 20 <= 320
 
 
+@pytest.mark.parametrize("two_pass", [False, True])
 @pytest.mark.parametrize("n,mod,nbytes", [(128, 4, 300), (256, 6, 700), (512, 2, 500), (1024, 6, 1304), (2048, 4, 3000), (4096, 8, 9000)])
-def test_sc_correlate_and_decode_long_periods(api, orc, n, mod, nbytes):
-    """Schmidl-Cox for L = 160 .. 5120 (chunk sums + bounded exact search) against the oracle over ALL lags of the capture
+def test_sc_correlate_and_decode_long_periods(api, orc, n, mod, nbytes, two_pass):
+    """Schmidl-Cox for L = 160 .. 5120 -- the streaming detector k_sc_stream, and (two_pass: tuning no_sc_stream) the chunk sums +
+    bounded exact search of kernels_scbig.hip -- against the oracle over ALL lags of the capture
     and over a bounded search, on frames through the FIR channel with delay, CFO and noise, on noise-only captures and on a
     capture cut inside the preamble; then the whole decode (N = 2048 / 4096 included: ADVICE r1).  Timing index, status and
     offset bit-exact, CFO to 1e-9, bytes exact."""
     rng = np.random.default_rng(7000 + n)
     S = n + n // 4
-    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=True)
+    ctx = api.Context(n_fft=n, modulation=mod, guard_bands=True, tuning={"no_sc_stream": int(two_pass)})
     D = ctx.data_symbols(nbytes)
     flen = ctx.frame_samples(nbytes)
     span = (flen + 3 * S // 2) // 2 * 2
@@ -914,7 +916,10 @@ def test_sc_correlate_and_decode_long_periods(api, orc, n, mod, nbytes):
     caps.append(cut)
     caps = np.stack(caps)
     for lags in (0, 2 * S):
-        d_hat, f_delta, metric = (host(v) for v in ctx.sc_correlate(dev(ctx, caps), n_lags=lags))
+        xd = dev(ctx, caps)
+        d_hat, f_delta, metric = (host(v) for v in ctx.sc_correlate(xd, n_lags=lags))
+        if xd.data_ptr() % 16 == 0:
+            assert ("k_sc_stream" in ctx.last_dispatch()) == (not two_pass), ctx.last_dispatch()
         for f in range(caps.shape[0]):
             wd, wp, wm, wfd = orc.sc_sync(wide(caps[f]), L=S, window_reps=3, n_lags=lags, threshold=0.5)
             assert d_hat[f] == wd, (n, lags, f, d_hat[f], wd)
