@@ -122,7 +122,7 @@ __device__ __forceinline__ void st_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ
 // DELAY = L / 640 when that is 1 or 2: the partner micro-chunk L samples earlier is the one the producer's lane read DELAY tiles
 // ago and stays in its registers (the LDS ring then holds only the tile being read and two in flight); 0: re-read from the ring.
 template <int DELAY>
-__global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
+__global__ __launch_bounds__(128, 3) void k_sc_stream(StParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     cf *ring = reinterpret_cast<cf *>(smem);                                  // [p.ring] samples: tile s in slot s % ring_tiles
     double *Ep = reinterpret_cast<double *>(ring + p.ring);                   // [epn] exclusive prefix of e over micro-chunks, index j % epn
@@ -152,6 +152,10 @@ __global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
     const bool prof = kProfile && p.debug >= 40;
     auto now = [&]() -> long long { return prof ? (long long)__builtin_amdgcn_s_memtime() : 0; };
 
+    // The two roles are two separate frame loops that execute the SAME sequence of barriers (written as one loop with the roles as
+    // branches the register allocator carried both roles' state through both bodies: 70 spilled registers, 1.8x slower, measured;
+    // with one frame loop around two role loops it still kept 35 registers more than the larger role needs).
+    if (wave == 1) {
     for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
         const cf *frame = p.in + f * p.frame_stride;
         // Stage tile s into ring slot s % ring_tiles (producer).  Whole tiles inside the capture go by LDS-DMA; a tile that touches
@@ -174,56 +178,6 @@ __global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
             }
             return false;
         };
-        // Lag-by-lag evaluation of interval k (lags 10 k .. 10 k + 9) from its boundary sums (consumer); the 4 x 9 samples of the slide
-        // come from global memory (L2 / MALL: the producer streamed them moments ago).  Over lags in [lo, hi]: the first lag with
-        // M >= threshold (INT_MAX: none) and the first maximum.  from_cross: the maximum only counts lags from this interval's own
-        // first crossing on (the search before the crossing: the lane that holds the wavefront's lowest crossing then already has
-        // the candidates of the peak window's first interval).
-        auto eval_interval = [&](bool active, int k, SSums x, long long lo, long long hi, bool from_cross, int &cross, SCand &best) {
-            cross = INT_MAX;
-            best = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
-            const long long d0 = 10LL * k;
-            // All 36 loads are UNCONDITIONAL, from an address that is always valid (the sample itself, or sample 0 of the frame for a
-            // lane / an index that must read as zero), and the zeros are selected afterwards: written as `cond ? frame[i] : 0` the
-            // compiler branches around every load and waits for it inside the branch -- 36 serialized round trips per evaluation
-            // (5-16 thousand cycles, measured) instead of one.
-            cf s0[9], s1[9], s2[9], s3[9];
-            {
-                bool ok0[9], ok1[9], ok2[9], ok3[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    const long long i0 = d0 + j, i1 = i0 + L, i2 = i0 + W, i3 = i2 + L;
-                    ok0[j] = active && i0 < p.frame_len; ok1[j] = active && i1 < p.frame_len;
-                    ok2[j] = active && i2 < p.frame_len; ok3[j] = active && i3 < p.frame_len;
-                    const cf *a0 = frame + (ok0[j] ? i0 : 0), *a1 = frame + (ok1[j] ? i1 : 0), *a2 = frame + (ok2[j] ? i2 : 0), *a3 = frame + (ok3[j] ? i3 : 0);
-                    s0[j] = *a0; s1[j] = *a1; s2[j] = *a2; s3[j] = *a3;
-                }
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    if (!ok0[j]) s0[j] = make_float2(0.f, 0.f);
-                    if (!ok1[j]) s1[j] = make_float2(0.f, 0.f);
-                    if (!ok2[j]) s2[j] = make_float2(0.f, 0.f);
-                    if (!ok3[j]) s3[j] = make_float2(0.f, 0.f);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const long long lag = d0 + j;
-                const double num = x.pr * x.pr + x.pi * x.pi, den = x.e * x.r;
-                if (active && lag >= lo && lag <= hi && den > 0.0) {
-                    if (cross == INT_MAX && num >= thr * den) cross = (int)lag;
-                    if (!from_cross || cross != INT_MAX) best = sc_pick(best, SCand{num, den, x.pr, x.pi, (int)lag});
-                }
-                if (j < 9) {
-                    const double r0 = s0[j].x, i0 = s0[j].y, r1 = s1[j].x, i1 = s1[j].y, r2 = s2[j].x, i2 = s2[j].y, r3 = s3[j].x, i3 = s3[j].y;
-                    x.pr += (r2 * r3 + i2 * i3) - (r0 * r1 + i0 * i1);
-                    x.pi += (r2 * i3 - i2 * r3) - (r0 * i1 - i0 * r1);
-                    x.e += (r2 * r2 + i2 * i2) - (r0 * r0 + i0 * i0);
-                    x.r += (r3 * r3 + i3 * i3) - (r1 * r1 + i1 * i1);
-                }
-            }
-        };
-
         // ---- producer state (wavefront 1)
         double run_e = 0.0, run_qr = 0.0, run_qi = 0.0;   // totals so far = Ep / Q at the next index
         int issued = 0;                                   // tiles issued so far
@@ -233,28 +187,6 @@ __global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
         for (int dly = 0; dly < (DELAY > 0 ? DELAY : 1); ++dly)
 #pragma unroll
             for (int i = 0; i < 5; ++i) xo[dly][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        // ---- consumer state (wavefront 0)
-        long long d1 = -1, hi = n - 1;                    // first crossing; last lag of the peak window
-        int k1 = 0, kE = INT_MAX;                         // interval of d1; interval of hi
-        int n_live = 0;
-        SCand best = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};     // the crossing's interval and every flushed list
-        SCand mybest = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};   // per lane: the exact boundary candidates this lane has met (merged once, at the end)
-        float best_lo = 0.f;                                  // LOWER bound of the best metric met so far (f32, rounded down): prunes the list
-        bool done = false;
-        // evaluate every interval on the live list exactly, fold the result into `best`, empty the list
-        auto flush_live = [&]() {
-            st_fence();
-            const bool act = lane < n_live;
-            const int k = act ? lk[lane] : 0;
-            const SSums x = act ? SSums{lsum[4 * lane], lsum[4 * lane + 1], lsum[4 * lane + 2], lsum[4 * lane + 3]} : SSums{0, 0, 0, 0};
-            int cr; SCand c;
-            eval_interval(act, k, x, d1, hi, false, cr, c);
-            best = sc_pick(best, sc_wave_best(c));
-            if (best.lag != INT_MAX) best_lo = fmaxf(best_lo, (float)(best.num / best.den) * 0.99999f);
-            n_live = 0;
-            st_fence();
-        };
-
         int s_stop = s_max;                               // tiles beyond this one are not needed (the consumer learns it with d1)
         // ring positions, advanced by one tile / 64 entries per step with a conditional wrap (no integer division in the loop)
         int slot_s = 0;                                   // i % ring_tiles (producer)
@@ -262,13 +194,7 @@ __global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
         int e_new = 0;                                    // (64 i) % epn: Ep entry ke + 1 goes to e_new + lane + 1
         int q_new = p.qn - (cL % p.qn);                   // (64 i - cL) mod qn
         if (q_new == p.qn) q_new = 0;
-        int e_k = p.epn - (cWL % p.epn);                  // (64 s - cWL) mod epn: interval k = 64 s - cWL + lane of the consumer's step s
-        if (e_k == p.epn) e_k = 0;
-        int q_k = p.qn - (cWL % p.qn);                    // (64 s - cWL) mod qn
-        if (q_k == p.qn) q_k = 0;
-        // The two roles run the SAME sequence of barriers from two separate loops (one loop with the roles as branches makes the
-        // register allocator carry both roles' state through both bodies: 70 spilled registers, 1.8x slower, measured).
-        if (wave == 1) {
+        {
             // the first two tiles go out before the frame's barrier: the ring belongs to the producer alone, and the consumer may
             // still be closing the previous frame's window
             st_wait_vm<0>();                              // (tiles of the previous frame issued beyond its last step)
@@ -286,9 +212,11 @@ __global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
                 if (dma0) { if (issued > i + 1 && dma1) st_wait_vm<ST_PIECES>(); else st_wait_vm<0>(); }
                 st_fence();
                 tb = now();
+                // Tile i + 2 is requested two tiles ahead.  DELAY == 0: into a slot of the L + 3-tile ring that nobody reads any more.
+                // DELAY > 0: the ring has TWO slots (25 instead of 30 KB of LDS per frame: six frames per CU), so it goes into tile i's own
+                // slot as soon as this lane's samples of tile i are in registers (below).
                 bool dma2 = false;
-                if (issued == i + 2 && issued < s_stop) { dma2 = issue(issued, slot_i); ++issued; }   // two tiles ahead, into a slot nobody reads any more
-                dma0 = dma1; dma1 = dma2;
+                if (DELAY == 0 && issued == i + 2 && issued < s_stop) { dma2 = issue(issued, slot_i); ++issued; }
                 // micro-chunk sums: e over samples [10 ke, 10 ke + 10) of this tile, q over [10 kq, ..) with partners L later (= this tile)
                 const int ke = 64 * i + lane, kq = ke - cL;
                 double se = 0.0, sqr = 0.0, sqi = 0.0;
@@ -309,6 +237,11 @@ __global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
 #pragma unroll
                         for (int j = 0; j < 5; ++j) y[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
+                    if (DELAY > 0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every lane's reads of tile i are done (one wavefront owns the ring)
+                        if (issued == i + 2 && issued < s_stop) { dma2 = issue(issued, slot_i); ++issued; }
+                    }
+                    dma0 = dma1; dma1 = dma2;
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {   // y = r[n], r[n + 1]; x = r[n + L], r[n + L + 1]
                         const double br = x[j].x, bi = x[j].y, dr = x[j].z, di = x[j].w;
@@ -344,7 +277,100 @@ __global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
                 if (stop || i >= s_stop) break;
             }
             if (prof && lane == 0) { ptk[0] = pt0; ptk[1] = pt1; ptk[2] = pt2; }
-        } else {
+        }
+        st_fence();
+    }
+    st_wait_vm<0>();
+    } else {
+    for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+        const cf *frame = p.in + f * p.frame_stride;
+        // Lag-by-lag evaluation of interval k (lags 10 k .. 10 k + 9) from its boundary sums (consumer); the 4 x 9 samples of the slide
+        // come from global memory (L2 / MALL: the producer streamed them moments ago).  Over lags in [lo, hi]: the first lag with
+        // M >= threshold (INT_MAX: none) and the first maximum.  from_cross: the maximum only counts lags from this interval's own
+        // first crossing on (the search before the crossing: the lane that holds the wavefront's lowest crossing then already has
+        // the candidates of the peak window's first interval).
+        auto eval_interval = [&](bool active, int k, SSums x, long long lo, long long hi, bool from_cross, int &cross, SCand &best) {
+            cross = INT_MAX;
+            best = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};
+            const long long d0 = 10LL * k;
+            // The loads are UNCONDITIONAL, from an address that is always valid (the sample itself, or sample 0 of the frame for a
+            // lane / an index that must read as zero), and the zeros are selected afterwards: written as `cond ? frame[i] : 0` the
+            // compiler branches around every load and waits for it inside the branch -- 36 serialized round trips per evaluation
+            // (5-16 thousand cycles, measured) instead of one.  They go in THREE batches of 12 (three slide steps each): all 36 at
+            // once cost 72 VGPRs and held the kernel at two waves per SIMD; three round trips per evaluation buy a third wave
+            // (six frames in flight per CU instead of four).
+#pragma clang loop unroll(disable)
+            for (int b3 = 0; b3 < 3; ++b3) {
+                cf s0[3], s1[3], s2[3], s3[3];
+                bool ok0[3], ok1[3], ok2[3], ok3[3];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    const long long i0 = d0 + 3 * b3 + jj, i1 = i0 + L, i2 = i0 + W, i3 = i2 + L;
+                    ok0[jj] = active && i0 < p.frame_len; ok1[jj] = active && i1 < p.frame_len;
+                    ok2[jj] = active && i2 < p.frame_len; ok3[jj] = active && i3 < p.frame_len;
+                    s0[jj] = ld_cf(frame + (ok0[jj] ? i0 : 0)); s1[jj] = ld_cf(frame + (ok1[jj] ? i1 : 0));
+                    s2[jj] = ld_cf(frame + (ok2[jj] ? i2 : 0)); s3[jj] = ld_cf(frame + (ok3[jj] ? i3 : 0));
+                }
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    if (!ok0[jj]) s0[jj] = make_float2(0.f, 0.f);
+                    if (!ok1[jj]) s1[jj] = make_float2(0.f, 0.f);
+                    if (!ok2[jj]) s2[jj] = make_float2(0.f, 0.f);
+                    if (!ok3[jj]) s3[jj] = make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    const long long lag = d0 + 3 * b3 + jj;
+                    const double num = x.pr * x.pr + x.pi * x.pi, den = x.e * x.r;
+                    if (active && lag >= lo && lag <= hi && den > 0.0) {
+                        if (cross == INT_MAX && num >= thr * den) cross = (int)lag;
+                        if (!from_cross || cross != INT_MAX) best = sc_pick(best, SCand{num, den, x.pr, x.pi, (int)lag});
+                    }
+                    const double r0 = s0[jj].x, i0 = s0[jj].y, r1 = s1[jj].x, i1 = s1[jj].y, r2 = s2[jj].x, i2 = s2[jj].y, r3 = s3[jj].x, i3 = s3[jj].y;
+                    x.pr += (r2 * r3 + i2 * i3) - (r0 * r1 + i0 * i1);
+                    x.pi += (r2 * i3 - i2 * r3) - (r0 * i1 - i0 * r1);
+                    x.e += (r2 * r2 + i2 * i2) - (r0 * r0 + i0 * i0);
+                    x.r += (r3 * r3 + i3 * i3) - (r1 * r1 + i1 * i1);
+                }
+            }
+            {   // the tenth lag: after the ninth slide step
+                const long long lag = d0 + 9;
+                const double num = x.pr * x.pr + x.pi * x.pi, den = x.e * x.r;
+                if (active && lag >= lo && lag <= hi && den > 0.0) {
+                    if (cross == INT_MAX && num >= thr * den) cross = (int)lag;
+                    if (!from_cross || cross != INT_MAX) best = sc_pick(best, SCand{num, den, x.pr, x.pi, (int)lag});
+                }
+            }
+        };
+
+        // ---- consumer state (wavefront 0)
+        long long d1 = -1, hi = n - 1;                    // first crossing; last lag of the peak window
+        int k1 = 0, kE = INT_MAX;                         // interval of d1; interval of hi
+        int n_live = 0;
+        SCand best = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};     // the crossing's interval and every flushed list
+        SCand mybest = SCand{-1.0, 1.0, 0.0, 0.0, INT_MAX};   // per lane: the exact boundary candidates this lane has met (merged once, at the end)
+        float best_lo = 0.f;                                  // LOWER bound of the best metric met so far (f32, rounded down): prunes the list
+        bool done = false;
+        // evaluate every interval on the live list exactly, fold the result into `best`, empty the list
+        auto flush_live = [&]() {
+            st_fence();
+            const bool act = lane < n_live;
+            const int k = act ? lk[lane] : 0;
+            const SSums x = act ? SSums{lsum[4 * lane], lsum[4 * lane + 1], lsum[4 * lane + 2], lsum[4 * lane + 3]} : SSums{0, 0, 0, 0};
+            int cr; SCand c;
+            eval_interval(act, k, x, d1, hi, false, cr, c);
+            best = sc_pick(best, sc_wave_best(c));
+            if (best.lag != INT_MAX) best_lo = fmaxf(best_lo, (float)(best.num / best.den) * 0.99999f);
+            n_live = 0;
+            st_fence();
+        };
+
+        int s_stop = s_max;                               // tiles beyond this one are not needed (the consumer learns it with d1)
+        int e_k = p.epn - (cWL % p.epn);                  // (64 s - cWL) mod epn: interval k = 64 s - cWL + lane of the consumer's step s
+        if (e_k == p.epn) e_k = 0;
+        int q_k = p.qn - (cWL % p.qn);                    // (64 s - cWL) mod qn
+        if (q_k == p.qn) q_k = 0;
+        {
             const long long t_frame = now();
             long long ct3 = 0, ct4 = 0, ct5 = 0;
             // ring positions of the consumer's first step, i0 - 1
@@ -484,14 +510,14 @@ __global__ __launch_bounds__(128, 2) void k_sc_stream(StParams p) {
         }
         st_fence();
     }
-    st_wait_vm<0>();
+    }
 }
 
 // LDS of one frame's workgroup: sample ring (the partner micro-chunk lives in registers when L is one or two tiles), prefix rings,
 // live list, control slots, profile ticks
 static size_t sc_stream_lds(int L, int W) {
     const int delay = (L % ST_T == 0 && L / ST_T <= 2) ? L / ST_T : 0;
-    const int ring = (delay ? 3 : (L + ST_T - 1) / ST_T + 3) * ST_T;
+    const int ring = (delay ? 2 : (L + ST_T - 1) / ST_T + 3) * ST_T;
     const int epn = (W + L) / 10 + 136, qn = W / 10 + 136;
     return (size_t)ring * sizeof(float2) + (size_t)(epn + 2 * qn) * sizeof(double) + (size_t)ST_LIVE * (4 * sizeof(double) + 8) + 32 + 32 + 64;
 }
@@ -510,8 +536,9 @@ hipError_t run_sc_stream(const ScParams &p, int num_cu, hipStream_t st) {
     q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride; q.frame_len = p.frame_len; q.n_lags = p.n_lags;
     q.L = p.L; q.W = p.W; q.threshold = p.threshold;
     const int delay = (p.L % ST_T == 0 && p.L / ST_T <= 2) ? p.L / ST_T : 0;
-    // samples kept for the partner micro-chunk (none when it lives in the producer's registers) + the tile being summed + two in flight
-    q.ring = (delay ? 3 : (p.L + ST_T - 1) / ST_T + 3) * ST_T;
+    // samples kept for the partner micro-chunk + the tile being summed + two in flight; with the partner in the producer's registers: two
+    // slots (the tile in flight, and the tile being summed whose slot is refilled as soon as its samples are in registers)
+    q.ring = (delay ? 2 : (p.L + ST_T - 1) / ST_T + 3) * ST_T;
     q.epn = (p.W + p.L) / 10 + 136; q.qn = p.W / 10 + 136;   // one step of history more than a step needs: producer and consumer overlap
     q.d_hat = p.d_hat; q.f_delta = p.f_delta; q.metric = p.metric;
     q.debug = kProfile ? tuning_or_default(p.tune).debug_sc : 0;
@@ -523,7 +550,7 @@ hipError_t run_sc_stream(const ScParams &p, int num_cu, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
-    if (per_cu > 4) per_cu = 4;   // two wavefronts per frame, built for two wavefronts per SIMD
+    if (per_cu > 6) per_cu = 6;   // two wavefronts per frame, built for three wavefronts per SIMD
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)num_cu * per_cu;
     const Tuning &tu = tuning_or_default(p.tune);
