@@ -831,9 +831,9 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
             dst[m] = *a;
         }
     };
-    // The image of symbol j is stored to HBM at the top of iteration j + 1, right after that iteration's samples have
-    // been taken out of the prefetch registers: loads and stores share the in-order VM counter, so stores issued just
-    // before the next wait-for-loads would be waited for as well.
+    // The image of symbol j is stored to HBM in iteration j + 1, behind that iteration's FIRST barrier (which is what makes the
+    // image complete: no barrier of its own) and long before the next wait for prefetched samples: loads and stores share the
+    // in-order VM counter, so stores issued just before a wait-for-loads would be waited for as well.
     auto flush = [&](unsigned *dst) { // image -> global, and clear it for the next symbol (same thread, same dwords)
         for (int i = tid; i < IMG_DW; i += 512) { dst[i] = img[i]; img[i] = 0u; }
     };
@@ -852,7 +852,6 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = (!FRAME || 64 * (t + 8 * m) < room_pre) ? pre[m] : make_float2(0.f, 0.f);
         fetch(sg + gridDim.x, pre, room_pre);
-        if (pending) flush(pending);
         bool live = true;
         if (FRAME) {
             if (p.nsym_frame && k >= p.nsym_frame[f]) live = false; // fewer symbols in this frame: nothing is written (workgroup-uniform)
@@ -867,7 +866,7 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
                 for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st); }
             }
         }
-        pending = live ? reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes) : nullptr;
+        unsigned *const mine = live ? reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes) : nullptr;
         // ---- stage A: FFT64 over a (wave-local)
         bfly8<false>(v);
 #pragma unroll
@@ -880,7 +879,9 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
         // v[q] = Y_b[c = t + 8 q]; twiddle and transpose
 #pragma unroll
         for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + (col ^ (t & 6))] = cmul(v[q], z[q]); // column XOR-swizzled by the row: conflict-free both ways
-        __syncthreads(); // T complete; the image is clear
+        __syncthreads(); // T complete; the PREVIOUS symbol's image complete (two barriers per symbol, not three: see below)
+        if (pending) flush(pending); // ... so it leaves for HBM here, cleared for this symbol's fields, which are written after the next barrier
+        pending = mine;
         // ---- stage B: FFT64 over b for row c = col
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = T[col * TS + (t ^ (col & 6)) + 8 * m]; // (t + 8 m) ^ s = (t ^ s) + 8 m for s < 8: offsets stay immediates
@@ -922,7 +923,12 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
             const float trn = tot * (0.5f / 256.0f); // mean of the 256 pilot angles, in turns -> hardware sin / cos
             rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn)); // applied inside the demapper
         }
-        // demodulate (src/receiver.rs:147-190) and pack LSB-first (src/utils.rs:30-36)
+        // demodulate (src/receiver.rs:147-190) and pack LSB-first (src/utils.rs:30-36).  The fields go into the image behind the pilot
+        // barrier, which also orders them after the flush of the previous image above; without guard bands there is no pilot
+        // barrier, so one stands here.  No barrier closes the step: the image is read (flushed) only behind the next step's first
+        // barrier, T is rewritten only by waves that are past the pilot barrier (every stage-B read of T lies before it), and the
+        // pilot sums are rewritten only behind the next step's first barrier.
+        if (!GUARD) __syncthreads();
         if (BPS == 8 || BPS == 4) {
             // Whole-byte / nibble fields: the 32 / BPS lane groups s that share a dword (same t, so the same carrier class)
             // merge their fields in registers -- lane ^ 8 by DPP, lane ^ 16 by ds_swizzle, lane ^ 32 by a shuffle -- and ONE
@@ -956,8 +962,8 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
                 }
             }
         }
-        __syncthreads(); // image complete; T / red are reused by the next symbol
     }
+    __syncthreads(); // the last image is complete
     if (pending) flush(pending);
 }
 

@@ -197,8 +197,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
             dst[e] = *a;
         }
     };
-    // The image of step j leaves for HBM at the top of step j + 1, right after that step's samples have been taken out of
-    // the prefetch registers (loads and stores share the in-order VM counter; see k_demod4096).
+    // The image of step j leaves for HBM in step j + 1, behind that step's first synchronisation (see k_demod4096).
     auto flush = [&](unsigned *dst) {
 #pragma unroll
         for (int i = l; i < IMG_DW; i += LPS) { dst[i] = myimg[i]; myimg[i] = 0u; }
@@ -219,7 +218,6 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = (!FRAME || elem(m) < room_pre) ? pre[m] : make_float2(0.f, 0.f);
         fetch(sg + stride, pre, room_pre);
-        if (pending) flush(pending);
         bool live = sg < p.total;
         if (FRAME) {
             if (live && p.nsym_frame && k >= p.nsym_frame[f]) live = false; // fewer symbols in this frame (short capture / failed sync): nothing is written
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
                 }
             }
         }
-        pending = live ? reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes) : nullptr;
+        unsigned *const mine = live ? reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes) : nullptr;
         // ---- stage A, twiddle, transpose
         stage_a<R, false>(v, tA, u);
 #pragma unroll
@@ -254,7 +252,9 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
             const int col = R >= 8 ? colA : colA + LPS * (e / R);
             T[(g * R + slot) * TS + col] = (R < 8 && e % R == 0) ? v[e] : cmul(v[e], z[e]);
         }
-        symbol_sync<LPS>(); // T complete
+        symbol_sync<LPS>(); // T complete; the PREVIOUS step's image complete (two synchronisations per step, not three: as k_demod4096)
+        if (pending) flush(pending); // ... so it leaves for HBM here and is cleared for this step's fields, which are written behind the next one
+        pending = mine;
         // ---- stage B: FFT64 over b for row cB
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = T[rs * TS + t + 8 * m];
@@ -292,6 +292,11 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
             const float trn = a * (0.5f / (4.0f * R)); // mean of the 4 R pilot angles, in turns -> hardware sin / cos
             rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn)); // applied inside the demapper
         }
+        // Fields go into the image behind the pilot barrier, which also orders them after the flush above; where there is none
+        // (no guard bands, or a symbol inside one wavefront) one stands here.  Nothing closes the step: the image is read only behind
+        // the next step's first synchronisation, T is rewritten only by wavefronts that are past this one (every stage-B read of T
+        // lies before it), the pilot sums only behind the next step's first.
+        if (!GUARD || LPS <= 64) symbol_sync<LPS>();
         // demodulate (src/receiver.rs:147-190) and pack LSB-first (src/utils.rs:30-36): OR every field into the image
         // A dead symbol (past the batch, or k >= nsym_frame[f]) must leave the image untouched: nothing flushes (and clears) it
         // after such a step, and demap_point(0) is not 0 for BPS >= 2 -- stale bits would be OR-ed into the next live symbol.
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
                 }
             }
         }
-        symbol_sync<LPS>(); // image complete; T / red are reused by the next step
     }
+    symbol_sync<LPS>(); // the last image is complete
     if (pending) flush(pending);
 }
 
@@ -407,24 +412,27 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
     }
     const int sym_bytes = ND * p.bps / 8;           // <= 64 R, a multiple of 4 (checked by the launcher)
     const bool aligned = (reinterpret_cast<uintptr_t>(p.bytes) & 3) == 0;
-    // stream bytes of symbol sg, two dwords per lane: issued without a branch (paydw_issue), settled where they are used
-    const bool want0 = 4 * l < sym_bytes, want1 = 4 * (l + LPS) < sym_bytes;
-    auto fetch = [&](long long sg, unsigned &d0, unsigned &d1) {
-        const long long base = sg * sym_bytes;
-        const bool in = sg < p.n_sym;
-        d0 = paydw_issue(p.bytes, base + 4 * l, p.n_bytes, in && want0, aligned, p.tw);
-        d1 = paydw_issue(p.bytes, base + 4 * (l + LPS), p.n_bytes, in && want1, aligned, p.tw);
+    // (The branch-free paydw_issue / paydw_settle form of k_tx4096 measured 13-20 % SLOWER in this kernel -- 0.59 -> 0.51 of the
+    // roofline at N = 64 .. 512, 0.49 -> 0.39 at N = 1024 -- so it keeps the conditional loads: the symbol after next is requested a
+    // whole step ahead and the wait lands where the step would wait for its LDS traffic anyway.)
+    auto dword = [&](long long by) -> unsigned {    // stream bytes by .. by + 3, zero past the end
+        if (aligned && by + 4 <= p.n_bytes) return *reinterpret_cast<const unsigned *>(p.bytes + by);
+        unsigned v = 0;
+        for (int j = 0; j < 4; ++j) if (by + j < p.n_bytes) v |= (unsigned)p.bytes[by + j] << (8 * j);
+        return v;
     };
-    auto settle = [&](long long sg, unsigned d0, unsigned d1) {
+    auto fetch = [&](long long sg, unsigned &d0, unsigned &d1) {
+        d0 = d1 = 0u;
+        if (sg >= p.n_sym) return;
         const long long base = sg * sym_bytes;
-        const bool in = sg < p.n_sym;
-        sbw[l] = paydw_settle(d0, p.bytes, base + 4 * l, p.n_bytes, in && want0, aligned);
-        sbw[l + LPS] = paydw_settle(d1, p.bytes, base + 4 * (l + LPS), p.n_bytes, in && want1, aligned);
+        if (4 * l < sym_bytes) d0 = dword(base + 4 * l);
+        if (4 * (l + LPS) < sym_bytes) d1 = dword(base + 4 * (l + LPS));
     };
     const long long stride = (long long)gridDim.x * G;
     unsigned d0, d1;
     fetch((long long)blockIdx.x * G + g, d0, d1);
-    settle((long long)blockIdx.x * G + g, d0, d1);
+    sbw[l] = d0;
+    sbw[l + LPS] = d1;
     if (l < 2) sbw[2 * LPS + l] = 0u;
     fetch((long long)blockIdx.x * G + g + stride, d0, d1);
     __syncthreads();
@@ -458,7 +466,8 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
             Tsym[slot * TS + col] = (R < 8 && e % R == 0) ? v[e] : cmul(v[e], z[e]);
         }
         symbol_sync<LPS>(); // T complete; every lane of the symbol is past the mapping stage
-        settle(sg + stride, d0, d1); // next symbol's bytes
+        sbw[l] = d0;        // next symbol's bytes
+        sbw[l + LPS] = d1;
         fetch(sg + 2 * stride, d0, d1);
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = T[rs * TS + t + 8 * m];
