@@ -22,6 +22,7 @@ struct Tuning {
     int no_rx1024_finish = 0;      // k_rxframe1024 writes raw bytes and k_rx_finish runs as its own launch
     long long grid_cap = 0;        // > 0: caps every persistent grid (test hook: many steps per workgroup on a small batch)
     int tx_waves = 16;             // k_txframe64: wavefronts per CU
+    int txframe_keep_steps = 1;    // k_txframe_mid: 1 = frames whose data symbols fit ONE workgroup step (<= 32 / R symbols) are built once, their points kept in registers until the maximum is known; 0 = always twice
     int sc_wg_per_cu = 7;          // k_sc_cf: persistent workgroups per CU
     int sc_first_lags = 384;       // k_sc_cf, searches of >= twice as many lags: the lags the first launch looks at (0 = one launch over every lag).
                                    // 384 = a crossing up to lag 143 with its whole window of W = 240 lags: a packet that starts within ~64 samples of its slot (config 3);

@@ -526,7 +526,9 @@ struct MidTxFrameParams {
     int bps;
 };
 
-template <int R, bool GUARD>
+// KEEP > 0: a round's symbols fit KEEP steps, so every lane KEEPS its KEEP x 8 points in registers while the round's maxima form and
+// the symbols are built ONCE (N = 128 / 256 / 512 frames of up to 16 / 16 / 16 data symbols); KEEP == 0: the two-pass scheme above.
+template <int R, bool GUARD, int KEEP>
 __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     typedef Mid<R> M;
     constexpr int N = M::N, S = M::S, CP = M::CP, LPS = M::LPS, G = M::G, Q = M::Q, TS = M::TS;
@@ -619,10 +621,77 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
         symbol_sync<LPS>(); // T and the byte window are free again
     };
 
+    // the samples of symbol (f0 + fl, k), divided by the frame's maximum, through T into sample order and out (prefix_block: out = [x[N - CP .. N), x[0 .. N)])
+    auto emit = [&](bool valid, long long f0, int fl, int k, const cf *v) {
+        const float mx = fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = cB + R * (t + 8 * q);
+            Tsym[(n >> 6) * TS + (n & 63)] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
+        }
+        symbol_sync<LPS>();
+        if (valid) {
+            float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride + (long long)(10 + k) * S);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = l + LPS * j, n = 2 * i;
+                const float4 y = *reinterpret_cast<const float4 *>(Tsym + (n >> 6) * TS + (n & 63));
+                dst4[(CP >> 1) + i] = y;
+                if (j == 3) dst4[i - ((N - CP) >> 1)] = y;
+            }
+        }
+        symbol_sync<LPS>();
+    };
+    auto note_max = [&](bool valid, int fl, const cf *v) {
+        float mine = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mine = fmaxf(mine, fmaxf(v[q].x, v[q].y) * (1.0f / N));
+        constexpr int WL = LPS < 64 ? LPS : 64;
+#pragma unroll
+        for (int sh = WL / 2; sh >= 1; sh >>= 1) mine = fmaxf(mine, __shfl_xor(mine, sh, 64));
+        if (valid && (l & (WL - 1)) == 0) atomicMax(&fmax[fl], __float_as_uint(mine));
+    };
+    // ---- header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
+    auto emit_headers = [&](long long f0) {
+        for (int fl = 0; fl < p.fpw && f0 + fl < p.n_frames; ++fl) {
+            const float mx = fmaxf(p.header_max, __uint_as_float(fmax[fl]));
+            float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride);
+            const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
+            for (int i = tid; i < 5 * S; i += 256) {
+                const float4 h = h4[i];
+                dst4[i] = make_float4(h.x / mx, h.y / mx, h.z / mx, h.w / mx);
+            }
+        }
+    };
+
     for (long long round = blockIdx.x; round < rounds; round += gridDim.x) {
         if (tid < 32) fmax[tid] = 0u;
         __syncthreads();
         const long long f0 = round * p.fpw;
+        if (KEEP > 0) { // steps <= KEEP (launcher): build once, keep, scale, store
+            cf vv[KEEP > 0 ? KEEP : 1][8];
+#pragma unroll
+            for (int step = 0; step < KEEP; ++step) {
+                if (step < steps) {
+                    const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
+                    const bool valid = sigma < slots && f0 + fl < p.n_frames;
+                    build(valid, f0 + fl, k, vv[step]);
+                    note_max(valid, fl, vv[step]);
+                }
+            }
+            __syncthreads();
+            emit_headers(f0);
+#pragma unroll
+            for (int step = 0; step < KEEP; ++step) {
+                if (step < steps) {
+                    const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
+                    const bool valid = sigma < slots && f0 + fl < p.n_frames;
+                    emit(valid, f0, fl, k, vv[step]);
+                }
+            }
+            __syncthreads(); // fmax is reset by the next round
+            continue;
+        }
         // pass 0: the signed maximum of every frame of the round; pass 1: the samples, divided by it.  ONE instance of the symbol
         // builder, the pass is a uniform branch around its two epilogues (two inlined instances spill at 4 waves per SIMD).
         for (int pass = 0; pass < 2; ++pass) {
@@ -631,67 +700,43 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
                 const bool valid = sigma < slots && f0 + fl < p.n_frames;
                 cf v[8];
                 build(valid, f0 + fl, k, v);
-                if (pass == 0) {
-                    float mine = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) mine = fmaxf(mine, fmaxf(v[q].x, v[q].y) * (1.0f / N));
-                    constexpr int WL = LPS < 64 ? LPS : 64;
-#pragma unroll
-                    for (int sh = WL / 2; sh >= 1; sh >>= 1) mine = fmaxf(mine, __shfl_xor(mine, sh, 64));
-                    if (valid && (l & (WL - 1)) == 0) atomicMax(&fmax[fl], __float_as_uint(mine));
-                    continue;
-                }
-                const float mx = fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int n = cB + R * (t + 8 * q);
-                    Tsym[(n >> 6) * TS + (n & 63)] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
-                }
-                symbol_sync<LPS>();
-                if (valid) { // prefix_block: out = [x[N - CP .. N), x[0 .. N)]
-                    float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride + (long long)(10 + k) * S);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = l + LPS * j, n = 2 * i;
-                        const float4 y = *reinterpret_cast<const float4 *>(Tsym + (n >> 6) * TS + (n & 63));
-                        dst4[(CP >> 1) + i] = y;
-                        if (j == 3) dst4[i - ((N - CP) >> 1)] = y;
-                    }
-                }
-                symbol_sync<LPS>();
+                if (pass == 0) { note_max(valid, fl, v); continue; }
+                emit(valid, f0, fl, k, v);
             }
             if (pass == 0) {
                 __syncthreads();
-                // ---- header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
-                for (int fl = 0; fl < p.fpw && f0 + fl < p.n_frames; ++fl) {
-                    const float mx = fmaxf(p.header_max, __uint_as_float(fmax[fl]));
-                    float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride);
-                    const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
-                    for (int i = tid; i < 5 * S; i += 256) {
-                        const float4 h = h4[i];
-                        dst4[i] = make_float4(h.x / mx, h.y / mx, h.z / mx, h.w / mx);
-                    }
-                }
+                emit_headers(f0);
             }
         }
         __syncthreads(); // fmax is reset by the next round
     }
 }
 
-template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, hipStream_t st, int num_cu, long long cap) {
+template <int R, int KEEP> static void launch_txframe_mid_k(const MidTxFrameParams &p, bool guard, dim3 grid, hipStream_t st) {
+    if (guard) hipLaunchKernelGGL((k_txframe_mid<R, true, KEEP>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_txframe_mid<R, false, KEEP>), grid, dim3(256), 0, st, p);
+}
+template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, hipStream_t st, int num_cu, long long cap, int keep_max) {
     constexpr int G = Mid<R>::G;
-    // frames per round: the count (<= 8, <= 32 slots' worth) that wastes the fewest symbol slots of the last step
-    int best = 1; double waste = 2.0;
-    for (int f = 1; f <= 8; ++f) {
-        const long long slots = (long long)f * p.D, padded = (slots + G - 1) / G * G;
-        const double wst = (double)(padded - slots) / (double)padded;
-        if (wst < waste - 1e-9) { waste = wst; best = f; }
+    // a frame whose symbols fit keep_max (<= 4) steps of the workgroup is built ONCE, its points kept in registers until the frame's
+    // maximum is known; otherwise frames per round: the count (<= 8, <= 32 slots' worth) that wastes the fewest symbol slots of
+    // the last step, and every symbol is built twice
+    const int steps1 = (p.D + G - 1) / G;
+    const int keep = (steps1 <= keep_max && steps1 <= 1) ? 1 : 0;   // KEEP = 2 / 4 instantiate the symbol builder 2 / 4 times: 18-170 spilled registers, not built
+    if (keep) p.fpw = 1;
+    else {
+        int best = 1; double waste = 2.0;
+        for (int f = 1; f <= 8; ++f) {
+            const long long slots = (long long)f * p.D, padded = (slots + G - 1) / G * G;
+            const double wst = (double)(padded - slots) / (double)padded;
+            if (wst < waste - 1e-9) { waste = wst; best = f; }
+        }
+        p.fpw = best;
     }
-    p.fpw = best;
     const long long rounds = (p.n_frames + p.fpw - 1) / p.fpw;
-    const long long grid = mid_grid(rounds, num_cu, 3, cap); // built for 3 waves per SIMD: the twice-inlined symbol builder spills at 4
-    if (guard) hipLaunchKernelGGL((k_txframe_mid<R, true>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_txframe_mid<R, false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)mid_grid(rounds, num_cu, 3, cap)); // built for 3 waves per SIMD: the twice-inlined symbol builder spills at 4
+    if (keep) launch_txframe_mid_k<R, 1>(p, guard, grid, st);
+    else launch_txframe_mid_k<R, 0>(p, guard, grid, st);
     return hipGetLastError();
 }
 
@@ -764,15 +809,18 @@ hipError_t run_txframe_mid(int n_fft, const SymParams &sp, const float2 *header,
     p.payload = sp.payload; p.payload_stride = sp.payload_stride; p.payload_len = sp.payload_len; p.payload_bytes = sp.payload_bytes;
     p.n_frames = sp.n_frames; p.D = sp.syms_per_frame; p.fpw = 1; p.tw = sp.tw; p.header = header; p.header_max = header_max;
     p.out = sp.out; p.out_stride = sp.out_stride_s; p.bps = sp.bps;
-    const long long cap = tuning_or_default(sp.tune).grid_cap;
-    trace_add(sp.trace, "k_txframe_mid");
+    const Tuning &tu = tuning_or_default(sp.tune);
+    const long long cap = tu.grid_cap;
+    const int keep_max = tu.txframe_keep_steps;   // 0 = always build twice (A/B)
+    const int G = 32 / R, steps1 = (p.D + G - 1) / G;
+    trace_add(sp.trace, (steps1 <= keep_max && steps1 <= 1) ? "k_txframe_mid<once>" : "k_txframe_mid");
     switch (R) {
-    case 1: return launch_txframe_mid<1>(p, sp.guard != 0, st, num_cu, cap);
-    case 2: return launch_txframe_mid<2>(p, sp.guard != 0, st, num_cu, cap);
-    case 4: return launch_txframe_mid<4>(p, sp.guard != 0, st, num_cu, cap);
-    case 8: return launch_txframe_mid<8>(p, sp.guard != 0, st, num_cu, cap);
-    case 16: return launch_txframe_mid<16>(p, sp.guard != 0, st, num_cu, cap);
-    case 32: return launch_txframe_mid<32>(p, sp.guard != 0, st, num_cu, cap);
+    case 1: return launch_txframe_mid<1>(p, sp.guard != 0, st, num_cu, cap, keep_max);
+    case 2: return launch_txframe_mid<2>(p, sp.guard != 0, st, num_cu, cap, keep_max);
+    case 4: return launch_txframe_mid<4>(p, sp.guard != 0, st, num_cu, cap, keep_max);
+    case 8: return launch_txframe_mid<8>(p, sp.guard != 0, st, num_cu, cap, keep_max);
+    case 16: return launch_txframe_mid<16>(p, sp.guard != 0, st, num_cu, cap, keep_max);
+    case 32: return launch_txframe_mid<32>(p, sp.guard != 0, st, num_cu, cap, keep_max);
     }
     return hipErrorNotSupported;
 }

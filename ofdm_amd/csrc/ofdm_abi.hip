@@ -411,6 +411,7 @@ const TuneKey kTuneKeys[] = {
     {"no_txframe64", &Tuning::no_txframe64, false},
     {"no_rx1024_finish", &Tuning::no_rx1024_finish, false},
     {"tx_waves", &Tuning::tx_waves, false},
+    {"txframe_keep_steps", &Tuning::txframe_keep_steps, false},
     {"sc_wg_per_cu", &Tuning::sc_wg_per_cu, false},
     {"sc_first_lags", &Tuning::sc_first_lags, false},
     {"demod64_wg_per_cu", &Tuning::demod64_wg_per_cu, false},

@@ -627,7 +627,9 @@ def test_tx_encode_mid_frames(api, orc, n, mod, guard, nbytes):
     pay = rng.integers(0, 256, (nfr, nbytes), dtype=np.uint8)
     frames = host(ctx.encode_batch(torch.from_numpy(pay).to(ctx.device), lens=torch.from_numpy(lens)))
     S, D = n + n // 4, ctx.data_symbols(nbytes)
-    assert ctx.last_dispatch() == ("k_txframe4096" if n == 4096 else "k_txframe_mid" if n > 64 or D > 56 else "k_txframe64")
+    # frames whose data symbols fit ONE workgroup step of the R x 64 kernel (D <= 32 / R) are built once, the others twice
+    mid = "k_txframe_mid<once>" if D <= 32 // (n // 64) else "k_txframe_mid"
+    assert ctx.last_dispatch() == ("k_txframe4096" if n == 4096 else mid if n > 64 or D > 56 else "k_txframe64")
     assert frames.shape == (nfr, (10 + D) * S)
     for f in range(nfr):
         # up to its own last data symbol the frame equals the oracle's frame for that payload: the pilot-only symbols that
