@@ -89,5 +89,5 @@ for nn, r in ((512, 8), (2048, 32)):
         "k_tx_mid_read_bytes_per_symbol": round(rd(f"ofdm::k_tx_mid<{r}, true>") / s, 1),
         "k_tx_mid_write_bytes_per_symbol": round(wr(f"ofdm::k_tx_mid<{r}, true>") / s, 1),
         "k_txframe_mid_frames": m["frames"],
-        "k_txframe_mid_write_over_frame_bytes": round(wr(f"ofdm::k_txframe_mid<{r}, true>") / m["frame_bytes"], 4)}
+        "k_txframe_mid_write_over_frame_bytes": round(wr(f"ofdm::k_txframe_mid<{r}, true, ") / m["frame_bytes"], 4)}
 print(json.dumps(out, indent=1))
