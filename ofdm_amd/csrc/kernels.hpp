@@ -24,6 +24,7 @@ struct Tuning {
     int tx_waves = 16;             // k_txframe64: wavefronts per CU
     int txframe_keep_steps = 1;    // k_txframe_mid: 1 = frames whose data symbols fit ONE workgroup step (<= 32 / R symbols) are built once, their points kept in registers until the maximum is known; 0 = always twice
     int sc_wg_per_cu = 7;          // k_sc_cf: persistent workgroups per CU
+    int sc128_one_wave = 1;        // k_sc_cf over <= 960 lags: one wavefront per frame (two chunks per lane, 15 frames per CU, no wavefront idling through the fine pass) instead of two (0: A/B); measured 1.46 -> 1.31 ms per 262 144 config-3 frames over all lags, 1.43 -> 1.25 bounded
     int sc_first_lags = 384;       // k_sc_cf, searches of >= twice as many lags: the lags the first launch looks at (0 = one launch over every lag).
                                    // 384 = a crossing up to lag 143 with its whole window of W = 240 lags: a packet that starts within ~64 samples of its slot (config 3);
                                    // later packets are found by the second launch.  Measured per 262 144 config-3 frames: 0 -> 1.81 ms, 320 -> 2.28, 384 -> 1.47, 448 .. 640 -> 1.52

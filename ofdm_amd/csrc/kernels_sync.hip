@@ -1003,6 +1003,14 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
             if (g1 > gcap) g1 = gcap;
             if (g1 > p.n_frames) g1 = p.n_frames;
             trace_add(p.trace, "k_sc_cf<128,first>");
+            if (tu.sc128_one_wave) { // one wavefront per frame (two chunks per lane): no idle second wavefront during the fine pass, LDS-bound 15 frames per CU
+                long long pc1 = (long long)(160 * 1024) / (long long)lds1;
+                if (pc1 > 16) pc1 = 16;
+                long long g1w = (long long)num_cu * pc1;
+                if (g1w > gcap) g1w = gcap;
+                if (g1w > p.n_frames) g1w = p.n_frames;
+                hipLaunchKernelGGL((k_sc_cf<128, 2, 4, 0, false>), dim3((unsigned)g1w), dim3(64), lds1, st, q1);
+            } else
             hipLaunchKernelGGL((k_sc_cf<128, 1, 5, 0, false>), dim3((unsigned)g1), dim3(128), lds1, st, q1);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             q.frame_list = redo_list; q.frame_count = redo_count;
@@ -1016,6 +1024,14 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         if (grid > gcap) grid = gcap;
         if (grid > p.n_frames) grid = p.n_frames;
         trace_add(p.trace, "k_sc_cf<128>");
+        if (tu.sc128_one_wave) {
+            per_cu = (long long)(160 * 1024) / (long long)lds;
+            if (per_cu > 16) per_cu = 16;
+            grid = (long long)num_cu * per_cu;
+            if (grid > gcap) grid = gcap;
+            if (grid > p.n_frames) grid = p.n_frames;
+            hipLaunchKernelGGL((k_sc_cf<128, 2, 4, 0, false>), dim3((unsigned)grid), dim3(64), lds, st, q);
+        } else
         hipLaunchKernelGGL((k_sc_cf<128, 1, 5, 0, false>), dim3((unsigned)grid), dim3(128), lds, st, q);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;

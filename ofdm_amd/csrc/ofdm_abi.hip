@@ -414,6 +414,7 @@ const TuneKey kTuneKeys[] = {
     {"txframe_keep_steps", &Tuning::txframe_keep_steps, false},
     {"sc_wg_per_cu", &Tuning::sc_wg_per_cu, false},
     {"sc_first_lags", &Tuning::sc_first_lags, false},
+    {"sc128_one_wave", &Tuning::sc128_one_wave, false},
     {"demod64_wg_per_cu", &Tuning::demod64_wg_per_cu, false},
     {"demod64_burst", &Tuning::demod64_burst, false},
     {"demod64_narrow_stores", &Tuning::demod64_narrow_stores, false},
