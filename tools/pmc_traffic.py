@@ -53,7 +53,7 @@ out = {
                   "note": "16 symbols x 512 B: the 128-byte cyclic prefix of every 640-byte symbol is never fetched"},
     "cfg3": {"frames": n, "capture_bytes_per_frame": cap3,
              "every_lag_k_sc_cf_256_read_bytes_per_frame": round(rd_max("ofdm::k_sc_cf<256, 2, 4, 0, false>") / n, 1),
-             "staged_first_lags_k_sc_cf_128_read_bytes_per_frame": round(rd("ofdm::k_sc_cf<128, 1, 5, 0, false>") / n, 1),
+             "staged_first_lags_k_sc_cf_128_read_bytes_per_frame": round(rd("ofdm::k_sc_cf<128, ") / n, 1),
              "staged_k_rxframe64_read_bytes_per_frame": round(rd("ofdm::k_rxframe64<6, true>") / n, 1),
              "staged_k_rxframe64_needed_bytes_per_frame": 21 * 512,
              "one_pass_k_sc_cf_read_bytes_per_frame": round(rd("ofdm::k_sc_cf<256, 2, 3, 6, true>") / n, 1),
