@@ -122,7 +122,7 @@ def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
                                   "frac": chain_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "per": "GPU (slowest rank)",
                                   "algorithmic_bytes_per_launch": chain_bytes,
                                   "kernels": "k_sc_cf<256,2,3,6,true> (one pass)" if one_pass else
-                                             "k_sc_cf<128,1,5,0> over the first lags + k_sc_cf<256,2,4,0> over the frames they do not determine (bounded: k_sc_cf<128,1,5,0> alone) + k_sc_post + k_sc_tile<list> + k_rx_prepare + k_rxframe64<6,true> (finish fused); see dispatch"}}
+                                             "k_sc_cf<128,2,4,0> (one wavefront per frame) over the first lags + k_sc_cf<256,2,4,0> over the frames they do not determine (bounded: k_sc_cf<128,2,4,0> alone) + k_sc_post + k_sc_tile<list> + k_rx_prepare + k_rxframe64<6,true> (finish fused); see dispatch"}}
         return r
 
     full = leg("full_chain_all_lags", 0, False)
