@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round profile set (run on the GPU box through gpurun, from the repo root; ROUND=r02 names the files):
+# Round profile set (run on the GPU box through gpurun, from the repo root; ROUND=r03 names the files):
 #   1. bench.py as the driver runs it                      -> gpurun_out/prof/${ROUND}_bench.json
 #   2. the same command under rocprofv3 --kernel-trace     -> ${ROUND}_bench_kernel_stats_ofdm_only.csv
 #   3. separate --pmc passes on tools/pmc_probe.py         -> ${ROUND}_pmc_*.tsv  (FETCH_SIZE / WRITE_SIZE / SQ sets, never
 #      combined with a trace: MI355X_MICROARCH.md, HBM + rocprofv3 sections)
 # rocprofv3 writes its (large) traces under /tmp; only the summaries are copied back.
 set -o pipefail
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 OUT="$PWD/gpurun_out/prof"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH_ARGS=${BENCH_ARGS:-}
