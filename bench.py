@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the config 3 / 4 / 5 reports (headline only)")
     ap.add_argument("--no-shapes", action="store_true", help="skip the per-length shapes block (N = 1 diagnostic)")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-buffer / long-capture blocks (N = 1 diagnostic)")
     ap.add_argument("--cfg3-frames", type=int, default=1_000_000, help="BASELINE config 3: 1M frames")
     ap.add_argument("--cfg4-ring", type=int, default=65536, help="config 4: frames in the resident ring")
     ap.add_argument("--cfg4-frames", type=int, default=10_000_000, help="config 4: frames counted (BASELINE: 10M-frame stream)")
@@ -299,11 +300,14 @@ def main():
     value = n_gpus * samples_per_step * a.steps / dt / 1e6
     kern_s = ev_ms / 1e3 / a.steps
     alg_bytes = F * (syms * ctx.S * 8 + syms * ctx.bytes_per_symbol)  # 8 B/sample read + packed bytes written
-    traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_traffic.json, newest round), scaled to F
-    for rnd in ("r03", "r02"):
+    # HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_traffic.json, newest round), scaled to F: collected in
+    # separate --pmc runs of tools/pmc_traffic.py (counters cannot ride along with a timed run), NOT measured in this run
+    traffic = traffic_source = None
+    for rnd in ("r04", "r03", "r02"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")))["k_demod64"]
             traffic = F * (pm["read_bytes_per_frame"] + pm["write_bytes_per_frame"])
+            traffic_source = f"profiles/{rnd}_pmc_traffic.json (FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.py on the same kernel and shape; not measured in this run)"
             break
         except Exception:
             pass
@@ -332,7 +336,7 @@ def main():
     except Exception as e:  # the headline must survive a failing probe
         box = {"box_probe_error": repr(e)}
     roof = {"bound": "hbm", "kernel": "ofdm::k_demod64<6, true, false, 16> (BPS, GUARD, HK, groups per store burst)" if headline_dispatch == "k_demod64<burst16>" else "ofdm::" + headline_dispatch, "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "unit": "GB/s", "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes, "dispatch": headline_dispatch, **box}
 
     res = {
@@ -341,7 +345,9 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "cfg2: 64-subcarrier 64QAM guard-band frames, RX demod only (CP strip+FFT64+pilot phase+demap)",
                    "frames_per_gpu": F, "symbols_per_frame": syms, "samples_per_frame": syms * ctx.S,
-                   "snr_db": a.snr_db, "parallelism": f"frame-index split x{n_gpus}, no collective"},
+                   "snr_db": a.snr_db, "parallelism": f"frame-index split x{n_gpus}, no collective",
+                   "parity": "FFT / CP strip / pilot phase follow src/receiver.rs:99-145; the 64-QAM demap is a north-star extension the reference "
+                             "lacks (EXT-1): parity unpinned by the reference, the oracle is the definition"},
         "ber_vs_tx_payload": ber, "frames_with_errors": nerr, "roofline": roof,
         "world_size_seen": world, "backend": grp.backend, "kernel_ms_per_rank": per_rank_ms,
     }
@@ -386,6 +392,14 @@ def main():
                 if oks < n_gpus:
                     res[name].setdefault("error", "another rank failed in this block")
                     break
+    if rank == 0 and n_gpus == 1 and not a.no_cfg3 and not a.no_host:
+        # host buffers in, host buffers out (the reference's own calling convention) and ONE long capture per decode: reported beside
+        # the resident numbers, never as `value`
+        try:
+            res.update(__import__("tools.bench_host", fromlist=["run"]).run(api, torch, local))
+        except Exception as e:
+            res["h2d_inclusive"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     if rank == 0 and n_gpus == 1 and not a.no_cfg3 and not a.no_shapes:
         # every transform length the library accepts: symbol-stream TX / RX and frame-level encode against their one-pass
         # rooflines (which lengths run shape-specialised kernels)

@@ -113,6 +113,10 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
                 ofdm_ctx **out);
 int ofdm_destroy(ofdm_ctx *ctx);
 int ofdm_set_stream(ofdm_ctx *ctx, void *stream);
+/* Give the context a non-blocking stream of its own (destroyed with it): what a host that runs several contexts side by side
+ * -- one thread per context, on one device or on several -- wants instead of the shared default stream ("one host
+ * thread + one stream per device"; include/ofdm_host.hpp ShardedContext). */
+int ofdm_use_own_stream(ofdm_ctx *ctx);
 int ofdm_synchronize(ofdm_ctx *ctx);
 int ofdm_last_hip_error(const ofdm_ctx *ctx); /* raw hipError_t of the last failing HIP call */
 /* Which kernels served the LAST stage-level / pipeline entry point on this context: the names of the kernels its launchers
@@ -239,7 +243,9 @@ int ofdm_rx_demod_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frames
 
 /* encode (src/transmitter.rs:11-58) for a batch: frame f = [lock][preamble x4][training x5][data symbols],
  * normalised per frame.  payload f = payload_dev[f*payload_stride .. + len_f), len_f = payload_len_dev[f] or
- * payload_bytes when NULL; every frame is laid out for payload_bytes (D = ofdm_data_symbols(payload_bytes))
+ * payload_bytes when NULL.  EVERY row, the last one included, must be READABLE for payload_bytes bytes whatever its len_f (the
+ * kernels prefetch whole rows and mask afterwards): payload_stride >= payload_bytes (OFDM_ERR_INVALID otherwise when n_frames > 1),
+ * and the buffer ends no earlier than the last row's payload_bytes.  Every frame is laid out for payload_bytes (D = ofdm_data_symbols(payload_bytes))
  * and written to out_dev[f*out_stride ..] (out_stride >= ofdm_frame_samples(payload_bytes)).
  * With ECC the payload is Hamming(7,4)-encoded first and the header carries the coded length. */
 int ofdm_tx_encode_batch(ofdm_ctx *ctx, const uint8_t *payload_dev, int64_t n_frames, int64_t payload_stride,
@@ -256,6 +262,57 @@ int ofdm_rx_decode_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frame
                          int64_t frame_len, int64_t n_lags, int32_t max_symbols, uint8_t *out_dev,
                          int64_t out_stride, int32_t *out_len_dev, int32_t *status_dev, int32_t *offset_dev,
                          double *f_delta_dev, float *metric_dev);
+
+/* ------------------------------------------------------------------ host buffers
+ * The reference's encode returns a host Vec<Complex64> and decode consumes one (src/transmitter.rs:11-15, src/receiver.rs:9-13).
+ * These entry points take HOST pointers and do the staging inside the library: the batch is cut into chunks of chunk_frames
+ * frames (<= 0: about 48 MB of samples) that move through three slots -- H2D of chunk k + 1 on a copy stream, the kernels of chunk k
+ * on the context's stream, D2H of chunk k - 1 on a second copy stream.  Page-locked caller memory (ofdm_host_alloc,
+ * ofdm_host_register) is DMA-ed in place; pageable memory is staged through pinned bounce buffers by the calling thread (slower:
+ * one extra host copy).  The calls are synchronous: results are in the caller's arrays when they return.  Same results, byte for
+ * byte, as the device-buffer entry points they wrap. */
+int ofdm_host_alloc(size_t bytes, void **host);   /* page-locked host memory (hipHostMalloc) */
+int ofdm_host_free(void *host);
+int ofdm_host_register(void *host, size_t bytes); /* page-lock memory the caller owns (a Rust Vec's buffer) for the time being */
+int ofdm_host_unregister(void *host);
+int ofdm_host_is_pinned(const void *host, size_t bytes); /* 1 when [host, host + bytes) can be DMA-ed in place */
+/* ofdm_rx_decode_batch on host buffers: frame f = in_host[f*frame_stride .. +frame_len) (frame_stride >= frame_len), outputs as there
+ * but in host arrays; offset / f_delta / metric may be NULL. */
+int ofdm_rx_decode_host(ofdm_ctx *ctx, const ofdm_fc32 *in_host, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                        int64_t n_lags, int32_t max_symbols, uint8_t *out_host, int64_t out_stride, int32_t *out_len_host,
+                        int32_t *status_host, int32_t *offset_host, double *f_delta_host, float *metric_host, int64_t chunk_frames);
+/* ofdm_rx_demod_batch on host buffers for regular streams (no offsets, no CFO, H == 1): the BASELINE metric's path. */
+int ofdm_rx_demod_host(ofdm_ctx *ctx, const ofdm_fc32 *in_host, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                       int32_t first_symbol, int32_t syms_per_frame, uint8_t *out_host, int64_t out_stride, int64_t chunk_frames);
+/* ofdm_tx_encode_batch on host buffers (payload_len_host may be NULL; row f is read for its own length only). */
+int ofdm_tx_encode_host(ofdm_ctx *ctx, const uint8_t *payload_host, int64_t n_frames, int64_t payload_stride,
+                        const int32_t *payload_len_host, int32_t payload_bytes, ofdm_fc32 *out_host, int64_t out_stride,
+                        int64_t chunk_frames);
+
+/* ------------------------------------------------------------------ one long capture
+ * The reference's receiver hands ONE long buffer to each decode! (examples/jetson_rx.rs:15-17,48-49,84-86: 2 000 000 samples) and
+ * looks for the packet anywhere in it (src/receiver.rs:20-25).  A batch of one such frame would occupy one workgroup; here the
+ * search runs as a batch of overlapping SLICES of the capture (slice_lags own lags each, <= 0: chosen by the library, plus a
+ * read-only halo of 2W + L samples).
+ *
+ * ofdm_sc_correlate_long: the Schmidl-Cox detection whose first threshold crossing d1 lies in [lag_lo, lag_hi) (lag_hi <= 0: the
+ * capture's last lag), with its whole peak window [d1, d1 + W] -- which may reach past lag_hi -- exactly as ONE search over the
+ * whole capture evaluates it.  *d_hat = the lag in the capture, -1 if none; f_delta / metric optional.  A host that splits the
+ * lags of one capture over several contexts / GPUs (ofdm_amd.dist.halo_ranges) takes the answer of the lowest range that has one.
+ * Synchronous; d_hat, f_delta, metric are HOST pointers. */
+int ofdm_sc_correlate_long(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_samples, int64_t lag_lo, int64_t lag_hi,
+                           int64_t slice_lags, int64_t *d_hat, double *f_delta, float *metric);
+/* decode (src/receiver.rs:9-96) of ONE long capture: the search above over [lag_lo, lag_hi) (skipped when d_hat_known >= 0: a
+ * detection merged from several contexts), then the receive chain from that frame on.  Identical to ofdm_rx_decode_batch with
+ * n_frames = 1 on the whole capture: status, offset (into the capture), CFO, metric, bytes.  out_dev[0 .. out_cap) is a DEVICE
+ * buffer (out_cap as out_stride there); out_len, status, offset, f_delta, metric are HOST pointers (the last three optional).
+ * With sync_mode = OFDM_SYNC_REFERENCE the lag range must be the whole capture. */
+int ofdm_rx_decode_long(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_samples, int64_t lag_lo, int64_t lag_hi,
+                        int64_t d_hat_known, int32_t max_symbols, uint8_t *out_dev, int64_t out_cap, int32_t *out_len,
+                        int32_t *status, int64_t *offset, double *f_delta, float *metric);
+/* the same from and to host memory: what `decode!(samples)` of a 2 M-sample Vec is */
+int ofdm_rx_decode_long_host(ofdm_ctx *ctx, const ofdm_fc32 *in_host, int64_t n_samples, int32_t max_symbols, uint8_t *out_host,
+                             int64_t out_cap, int32_t *out_len, int32_t *status, int64_t *offset, double *f_delta, float *metric);
 
 /* ------------------------------------------------------------------ loop-back test bench
  * channel (src/channel.rs:33-74), per frame:

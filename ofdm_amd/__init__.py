@@ -9,7 +9,7 @@ from ._lib import load, LIB_PATH, Params, SIGNATURES  # noqa: F401
 
 def __getattr__(name):
     # api imports torch and touches the GPU lazily; keep `import ofdm_amd` cheap
-    if name in ("api", "Context", "encode", "decode", "channel", "default_pilots", "locking_signal", "preamble",
+    if name in ("api", "Context", "encode", "decode", "decode_long", "pinned_empty", "channel", "default_pilots", "locking_signal", "preamble",
                 "training_signals", "OfdmError", "DecodeError", "BPSK", "QPSK", "QAM16", "QAM64", "QAM256",
                 "ECC_NONE", "ECC_HAMMING74", "CFO_OFF", "CFO_SIGNED", "CFO_ABS", "SYNC_SCHMIDL_COX", "SYNC_REFERENCE"):
         import importlib

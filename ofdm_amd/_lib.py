@@ -48,6 +48,7 @@ SIGNATURES = {
     "ofdm_create": (C.c_int, [C.POINTER(Params), vp, vp, C.c_int, vp, C.POINTER(vp)]),
     "ofdm_destroy": (C.c_int, [vp]),
     "ofdm_set_stream": (C.c_int, [vp, vp]),
+    "ofdm_use_own_stream": (C.c_int, [vp]),
     "ofdm_synchronize": (C.c_int, [vp]),
     "ofdm_last_hip_error": (C.c_int, [vp]),
     "ofdm_last_dispatch": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
@@ -83,6 +84,19 @@ SIGNATURES = {
     "ofdm_xcorr_batch": (C.c_int, [vp, vp, i64, i64, i64, vp, i32, vp, vp, vp, i64]),
     "ofdm_channel_batch": (C.c_int, [vp, vp, i64, i64, i64, C.c_double, i32, C.c_uint64, vp, vp, vp, i64, i64, vp]),
     "ofdm_channel_taps": (C.c_int, [vp]),
+    "ofdm_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+    "ofdm_host_free": (C.c_int, [vp]),
+    "ofdm_host_register": (C.c_int, [vp, C.c_size_t]),
+    "ofdm_host_unregister": (C.c_int, [vp]),
+    "ofdm_host_is_pinned": (C.c_int, [vp, C.c_size_t]),
+    "ofdm_rx_decode_host": (C.c_int, [vp, vp, i64, i64, i64, i64, i32, vp, i64, vp, vp, vp, vp, vp, i64]),
+    "ofdm_rx_demod_host": (C.c_int, [vp, vp, i64, i64, i64, i32, i32, vp, i64, i64]),
+    "ofdm_tx_encode_host": (C.c_int, [vp, vp, i64, i64, vp, i32, vp, i64, i64]),
+    "ofdm_sc_correlate_long": (C.c_int, [vp, vp, i64, i64, i64, i64, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_float)]),
+    "ofdm_rx_decode_long": (C.c_int, [vp, vp, i64, i64, i64, i64, i32, vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_float)]),
+    "ofdm_rx_decode_long_host": (C.c_int, [vp, vp, i64, i32, vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "ofdm_hbm_read_probe": (C.c_int, [vp, vp, i64, i32]),
     "ofdm_timer_start": (C.c_int, [vp]),
     "ofdm_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),

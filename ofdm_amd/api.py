@@ -98,6 +98,26 @@ def training_signals(length: int = 64) -> np.ndarray:
     return default_pilots(length)[1]
 
 
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """A numpy array in page-locked host memory (ofdm_host_alloc): what the host-buffer entry points DMA in place.  The memory
+    is returned to the driver when the array (and every view of it) is gone."""
+    import weakref
+
+    lib = _lib.load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = C.c_void_p()
+    _check(lib, lib.ofdm_host_alloc(max(n, 1), C.byref(ptr)), "ofdm_host_alloc")
+    buf = (C.c_char * max(n, 1)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=np.uint8, count=n).view(dt).reshape(shape)
+    weakref.finalize(buf, lib.ofdm_host_free, C.c_void_p(ptr.value))
+    return arr
+
+
+def _host(a: Optional[np.ndarray]):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
 def _dev(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -435,6 +455,82 @@ class Context:
                  "channel")
         return (out, fdo) if want_f_delta else out
 
+    # ---------------------------------------------------------------- one long capture (examples/jetson_rx.rs:15-17,84-86)
+    def sc_correlate_long(self, capture: torch.Tensor, lag_lo: int = 0, lag_hi: int = 0, slice_lags: int = 0):
+        """ofdm_sc_correlate_long: the Schmidl-Cox detection of ONE capture whose first crossing lies in [lag_lo, lag_hi)
+        (lag_hi = 0: up to the last lag), searched as a batch of overlapping slices -> (d_hat or -1, f_delta, metric)."""
+        x = self._cx(capture).reshape(-1)
+        d, fd, m = C.c_int64(), C.c_double(), C.c_float()
+        self._ck(self.lib.ofdm_sc_correlate_long(self.h, _dev(x), x.numel(), lag_lo, lag_hi, slice_lags, C.byref(d), C.byref(fd),
+                                                 C.byref(m)), "sc_correlate_long")
+        return int(d.value), float(fd.value), float(m.value)
+
+    def decode_long(self, capture: torch.Tensor, max_symbols: int, lag_lo: int = 0, lag_hi: int = 0, d_hat_known: int = -1):
+        """ofdm_rx_decode_long: decode (src/receiver.rs:9-96) of ONE long capture on the device -> dict(bytes, len, status, offset,
+        f_delta, metric), the result of decode_batch on the whole capture as a single frame."""
+        x = self._cx(capture).reshape(-1)
+        ob = max(max_symbols * self.bytes_per_symbol - 16, 4)
+        out = self.empty((ob,), torch.uint8)
+        ln, st, off, fd, m = C.c_int32(), C.c_int32(), C.c_int64(), C.c_double(), C.c_float()
+        self._ck(self.lib.ofdm_rx_decode_long(self.h, _dev(x), x.numel(), lag_lo, lag_hi, d_hat_known, max_symbols, _dev(out), ob,
+                                              C.byref(ln), C.byref(st), C.byref(off), C.byref(fd), C.byref(m)), "rx_decode_long")
+        return {"bytes": out, "len": int(ln.value), "status": int(st.value), "offset": int(off.value), "f_delta": float(fd.value),
+                "metric": float(m.value)}
+
+    def decode_long_host(self, capture: np.ndarray, max_symbols: int):
+        """ofdm_rx_decode_long_host: the same from a host array of complex64 (pinned_empty() memory is DMA-ed in place)."""
+        x = np.ascontiguousarray(capture, dtype=np.complex64).reshape(-1)
+        ob = max(max_symbols * self.bytes_per_symbol - 16, 4)
+        out = np.zeros(ob, np.uint8)
+        ln, st, off, fd, m = C.c_int32(), C.c_int32(), C.c_int64(), C.c_double(), C.c_float()
+        self._ck(self.lib.ofdm_rx_decode_long_host(self.h, _host(x), x.size, max_symbols, _host(out), ob, C.byref(ln), C.byref(st),
+                                                   C.byref(off), C.byref(fd), C.byref(m)), "rx_decode_long_host")
+        return {"bytes": out, "len": int(ln.value), "status": int(st.value), "offset": int(off.value), "f_delta": float(fd.value),
+                "metric": float(m.value)}
+
+    # ---------------------------------------------------------------- host buffers (H2D / kernels / D2H pipelined in the library)
+    def decode_host(self, frames: np.ndarray, max_symbols: int, n_lags: int = 0, frame_len: Optional[int] = None,
+                    chunk_frames: int = 0, out: Optional[dict] = None):
+        """ofdm_rx_decode_host: decode_batch for a host array [n_frames, stride] of complex64 -> dict of host arrays."""
+        x = frames if frames.dtype == np.complex64 and frames.flags.c_contiguous else np.ascontiguousarray(frames, dtype=np.complex64)
+        n, stride = x.shape
+        ob = max(max_symbols * self.bytes_per_symbol - 16, 4)
+        res = out or {"bytes": np.zeros((n, ob), np.uint8), "len": np.zeros(n, np.int32), "status": np.zeros(n, np.int32),
+                      "offset": np.zeros(n, np.int32), "f_delta": np.zeros(n, np.float64), "metric": np.zeros(n, np.float32)}
+        self._ck(self.lib.ofdm_rx_decode_host(self.h, _host(x), n, stride, stride if frame_len is None else frame_len, n_lags,
+                                              max_symbols, _host(res["bytes"]), res["bytes"].shape[1], _host(res["len"]),
+                                              _host(res["status"]), _host(res["offset"]), _host(res["f_delta"]), _host(res["metric"]),
+                                              chunk_frames), "rx_decode_host")
+        return res
+
+    def demod_host(self, frames: np.ndarray, syms_per_frame: int, first_symbol: int = 0, chunk_frames: int = 0,
+                   out: Optional[np.ndarray] = None) -> np.ndarray:
+        """ofdm_rx_demod_host: rx_demod of regular streams for a host array [n_frames, stride] -> uint8 [n_frames, bytes]."""
+        x = frames if frames.dtype == np.complex64 and frames.flags.c_contiguous else np.ascontiguousarray(frames, dtype=np.complex64)
+        n, stride = x.shape
+        nb = syms_per_frame * self.bytes_per_symbol
+        out = np.zeros((n, nb), np.uint8) if out is None else out
+        self._ck(self.lib.ofdm_rx_demod_host(self.h, _host(x), n, stride, stride, first_symbol, syms_per_frame, _host(out),
+                                             out.shape[1], chunk_frames), "rx_demod_host")
+        return out
+
+    def encode_host(self, payload: np.ndarray, lens: Optional[np.ndarray] = None, chunk_frames: int = 0,
+                    out: Optional[np.ndarray] = None) -> np.ndarray:
+        """ofdm_tx_encode_host: encode_batch for a host array [n_frames, payload_bytes] of uint8 -> complex64 [n_frames, frame]."""
+        pay = np.ascontiguousarray(payload, dtype=np.uint8)
+        n, nbytes = pay.shape
+        frame = self.frame_samples(nbytes)
+        out = np.zeros((n, frame), np.complex64) if out is None else out
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.int32)
+        self._ck(self.lib.ofdm_tx_encode_host(self.h, _host(pay), n, nbytes, _host(lens), nbytes, _host(out), out.shape[1],
+                                              chunk_frames), "tx_encode_host")
+        return out
+
+    def use_own_stream(self):
+        """ofdm_use_own_stream: a non-blocking stream owned by this context (several contexts side by side on one device)."""
+        self._ck(self.lib.ofdm_use_own_stream(self.h), "ofdm_use_own_stream")
+
     def hbm_read_probe(self, samples: torch.Tensor, pattern: int = 0):
         """Measurement helper: read-only pass over a buffer of 80-sample symbols in the demod kernel's access pattern (0),
         over whole symbols (1) or with unit-stride 16-byte loads (2)."""
@@ -455,8 +551,10 @@ class Context:
 _CTX_CACHE = {}
 
 
-def _ctx(n_fft, modulation, guard_bands, ecc=ECC_NONE, **kw) -> Context:
-    key = (n_fft, modulation, bool(guard_bands), ecc, tuple(sorted(kw.items())))
+def _ctx(n_fft, modulation, guard_bands, ecc=ECC_NONE, _replica: int = 0, **kw) -> Context:
+    """One cached context per parameter set (and replica index): the free functions never pay ofdm_create -- table uploads,
+    workspace growth -- more than once."""
+    key = (n_fft, modulation, bool(guard_bands), ecc, _replica, tuple(sorted(kw.items())))
     if key not in _CTX_CACHE:
         _CTX_CACHE[key] = Context(n_fft=n_fft, modulation=modulation, guard_bands=guard_bands, ecc=ecc, **kw)
     return _CTX_CACHE[key]
@@ -501,3 +599,36 @@ def decode(samples, guard_bands: Optional[bool] = None, modulation: Optional[int
                            FRAME_BADTIMING: "timing offset outside the capture (the reference panics in split_off)"}.get(status, "decode failed"))
     n = int(res["len"][0])
     return bytes(res["bytes"][0, :n].cpu().numpy())
+
+
+def decode_long(samples, guard_bands: Optional[bool] = None, modulation: Optional[int] = None, n_fft: int = 64,
+                ecc: int = ECC_NONE, world: int = 1, max_symbols: Optional[int] = None, device: int = 0, **sync):
+    """`ofdm::decode!` of ONE long capture (the 2 M-sample buffers of examples/jetson_rx.rs:15-17,48-49,84-86) on the HIP path.
+    world > 1 rehearses the multi-GPU halo split on one device: `world` contexts, context r searching the lags
+    dist.lag_ranges(...)[r] of the shared capture (ofdm_sc_correlate_long), the lowest range with a detection wins
+    (dist.merge_first_detection), and that context runs the receive chain (ofdm_rx_decode_long with the merged detection).
+    Returns dict(bytes, len, status, offset, f_delta, metric); raises DecodeError where the reference returns Err."""
+    from . import dist
+
+    mod = BPSK if modulation is None else modulation
+    ctxs = [_ctx(n_fft, mod, bool(guard_bands), ecc, device=device, _replica=r, **sync) for r in range(max(world, 1))]
+    c0 = ctxs[0]
+    x = samples if isinstance(samples, torch.Tensor) else c0.to_device(np.asarray(samples))
+    x = x.reshape(-1)
+    if max_symbols is None:
+        max_symbols = max((x.numel() + c0.S - 1) // c0.S - 10, 1)
+    if world <= 1 or c0.params.sync_mode != SYNC_SCHMIDL_COX:
+        res = c0.decode_long(x, max_symbols)
+    else:
+        L, W = c0.S, c0.params.sync_window_reps * c0.S
+        dets = []
+        for (lo, hi), c in zip(dist.lag_ranges(x.numel(), world, L, W), ctxs):
+            d, fd, m = c.sc_correlate_long(x, lo, hi) if hi > lo else (-1, 0.0, 0.0)
+            dets.append((0, hi, d, fd, m))  # d is already a lag of the whole capture
+        d, fd, m = dist.merge_first_detection(dets)
+        winner = next((c for c, det in zip(ctxs, dets) if det[2] >= 0), c0)
+        res = winner.decode_long(x, max_symbols, d_hat_known=d) if d >= 0 else {
+            "bytes": c0.empty((4,), torch.uint8), "len": 0, "status": FRAME_NOSYNC, "offset": 0, "f_delta": 0.0, "metric": 0.0}
+    if res["status"] == FRAME_SHORT:
+        raise DecodeError("Input not long enough, bailing early")
+    return res

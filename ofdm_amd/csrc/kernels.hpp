@@ -111,10 +111,10 @@ hipError_t run_demod64_fast(const SymParams &p, hipStream_t st, int num_cu);
 hipError_t run_demod4096(const SymParams &p, hipStream_t st, int num_cu);
 // fused estimate_channel + per-symbol demod [+ finish] for N = 1024 frames (16 x 64 FFT, kernels_rx1024.hip), the N = 1024
 // analogue of run_rxframe64.  final_* (optional): length header, truncate and Hamming decode done by the same kernel when the
-// frame's packed bytes fit its LDS image; *fused_out reports whether they were (else the caller runs k_rx_finish).
+// frame's packed bytes fit its LDS image; *fused_out reports whether they were (else the caller runs k_rx_finish).  A frame that
+// must not be decoded is one with nsym_frame[f] == 0 (the prepare kernels guarantee it for every status != 0).
 hipError_t run_rxframe1024(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu, unsigned char *final_out = nullptr,
-                           long long final_stride = 0, int32_t *final_len = nullptr, const int32_t *status = nullptr, int ecc = 0,
-                           bool *fused_out = nullptr);
+                           long long final_stride = 0, int32_t *final_len = nullptr, int ecc = 0, bool *fused_out = nullptr);
 // N = 4096 continuous-stream TX (map + IFFT + CP) as 64 x 64; needs tx_raw_total >= 0
 hipError_t run_tx4096(const SymParams &p, hipStream_t st, int num_cu);
 hipError_t run_txframe4096(const SymParams &p, const float2 *header, float header_max, hipStream_t st, int num_cu);

@@ -344,10 +344,12 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
 }
 
 // Fused channel estimate + demod [+ finish] for N = 1024 frames.  hipErrorNotSupported => caller uses run_chest + run_demod.
-// final_out / final_stride / final_len / status / ecc (optional, rows 4-byte aligned): the kernel also does the finish
+// final_out / final_stride / final_len / ecc (optional, rows 4-byte aligned): the kernel also does the finish
 // (length header, truncate, Hamming decode) when a frame's packed bytes fit its LDS image; *fused_out says whether it did.
+// CONTRACT of the fused finish: a frame that must not be decoded has nsym_frame[f] == 0 -- that, not a status array, is what
+// zeroes its final_len (k_rx_prepare / k_rx_prepare_ref write nsym = 0 whenever status != 0).
 hipError_t run_rxframe1024(const SymParams &sp, float2 *hk_out, hipStream_t st, int num_cu, unsigned char *final_out,
-                           long long final_stride, int32_t *final_len, const int32_t *status, int ecc, bool *fused_out) {
+                           long long final_stride, int32_t *final_len, int ecc, bool *fused_out) {
     if (fused_out) *fused_out = false;
     if (!sp.nsym_frame || sp.soft) return hipErrorNotSupported;
     const int nd = sp.guard ? 48 * 16 : 1024;
@@ -360,7 +362,6 @@ hipError_t run_rxframe1024(const SymParams &sp, float2 *hk_out, hipStream_t st, 
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.hk = hk_out;
     p.aligned = (reinterpret_cast<uintptr_t>(sp.in) & 15) == 0 && (sp.frame_stride & 1) == 0;
     p.final_out = nullptr; p.final_stride = 0; p.final_len = nullptr; p.ecc = ecc;
-    (void)status;
     // the frame's packed bytes (at most max_symbols symbols: out_stride of the raw rows) must fit the LDS image
     const bool fuse = final_out && final_len && (reinterpret_cast<uintptr_t>(final_out) & 3) == 0 && (final_stride & 3) == 0 &&
                       sp.out_stride <= (long long)RX_RAW_DW * 4 && !tuning_or_default(sp.tune).no_rx1024_finish;

@@ -988,13 +988,16 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         // first + W + L samples instead of the slot -- and lists the frames they do not determine (no crossing there, or a window
         // that reaches beyond); launch 2 is the whole search over that list.  Results are those of the whole search on every frame.
         const int first = tu.sc_first_lags;
-        bool two_phase = first > 0 && p.n_lags >= 2LL * first && (long long)128 * 10 - p.W - p.L >= first && first > p.W + 1;
+        // (the first launch's tile is 128 chunks = 1280 samples: first + W + L + 11 samples must fit it, or the kernel's arrays behind the
+        // samples would leave the LDS allocation)
+        bool two_phase = first > 0 && p.n_lags >= 2LL * first && (long long)128 * 10 - p.W - p.L - 12 >= first && first > p.W + 1;
         if (two_phase) {
             if ((e = hipMemsetAsync(redo_count, 0, 16, st)) != hipSuccess) return e;
             ScFastParams q1 = q;
             q1.n_lags = first; q1.defer = 1;
             long long stage1 = (first + p.W + p.L + 10 + 1) & ~1LL;
             if (stage1 > p.frame_len) stage1 = p.frame_len & ~1LL;
+            if (stage1 > 1280) stage1 = 1280;
             q1.n16 = (int)(stage1 / 2);
             const size_t lds1 = sc_cf_lds_bytes(p.L, 128, stage1, false);
             long long pc = (long long)(160 * 1024) / (long long)lds1;

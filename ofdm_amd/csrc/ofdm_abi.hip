@@ -1,8 +1,7 @@
 // ofdm_abi.hip -- the extern "C" boundary of libofdm_hip.so (include/ofdm_hip.h).
 // Context, parameter validation, host-side constant tables (f64 -> f32), workspace and the orchestration of
 // the TX / RX pipelines.  No exceptions cross the boundary; every HIP failure is mapped to OFDM_ERR_HIP.
-#include "../../include/ofdm_hip.h"
-#include "kernels.hpp"
+#include "ofdm_ctx.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -16,11 +15,6 @@ int sc_tile_lags();
 using namespace ofdm;
 
 namespace {
-
-struct Workspace {
-    void *ptr = nullptr;
-    size_t cap = 0;
-};
 
 constexpr double kPi = 3.14159265358979323846;
 
@@ -62,62 +56,6 @@ static double uniform_pm1(uint64_t &s) { return (double)(splitmix64(s) >> 11) * 
 static bool valid_nfft(int n) { return n >= 64 && n <= 4096 && (n & (n - 1)) == 0; }
 
 } // namespace
-
-struct ofdm_ctx {
-    ofdm_params prm;
-    int device = 0;
-    int num_cu = 256;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int last_hip = 0;
-    // constant device tables
-    float2 *d_tw = nullptr;       // exp(-2 pi i m / N)
-    float2 *d_inv_trn = nullptr;  // 1 / training[k]
-    float2 *d_header = nullptr;   // 10 * S un-normalised header samples
-    double *d_atan_tab = nullptr; // 32 x (cos, sin)(k pi / 16): the fused receive kernel's f64 atan2 (kernels_sync.hip)
-    float header_max = 0.f;
-    Tuning tune;                  // ofdm_set_tuning: per-context A/B switches and grid shapes (no environment variable is read)
-    Trace trace;                  // ofdm_last_dispatch: the kernels the last entry point launched
-    // workspaces (grown on demand, never inside a captured region)
-    Workspace ws[8];
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-    int S() const { return prm.n_fft + prm.cp_len; }
-    int carriers() const { return prm.guard_bands ? 48 * (prm.n_fft / 64) : prm.n_fft; }
-    int bytes_per_symbol() const { return carriers() * prm.modulation / 8; }
-};
-
-// Scoped device selection: every entry point that touches HIP runs on its context's device and leaves the calling
-// thread's current device as it found it (one thread may hold contexts on several GPUs; torch shares the thread's device).
-struct DeviceGuard {
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceGuard(int device) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
-    }
-    ~DeviceGuard() { if (switched) hipSetDevice(prev); }
-    DeviceGuard(const DeviceGuard &) = delete;
-    DeviceGuard &operator=(const DeviceGuard &) = delete;
-};
-
-#define HIP_TRY(ctx, expr)                                   \
-    do {                                                     \
-        hipError_t _e = (expr);                              \
-        if (_e != hipSuccess) { (ctx)->last_hip = (int)_e; return OFDM_ERR_HIP; } \
-    } while (0)
-
-static int ws_get(ofdm_ctx *c, int slot, size_t bytes, void **out) {
-    Workspace &w = c->ws[slot];
-    if (bytes > w.cap) {
-        if (w.ptr) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(w.ptr)); w.ptr = nullptr; w.cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&w.ptr, want);
-        if (e != hipSuccess) { c->last_hip = (int)e; w.ptr = nullptr; return OFDM_ERR_NOMEM; }
-        w.cap = want;
-    }
-    *out = w.ptr;
-    return OFDM_OK;
-}
 
 static SymParams base_params(ofdm_ctx *c) {
     SymParams p;
@@ -282,6 +220,7 @@ int ofdm_destroy(ofdm_ctx *c) {
     const bool have_prev = hipGetDevice(&prev_dev) == hipSuccess;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    ofdm_host_pipe_destroy(c);
     for (auto &w : c->ws) if (w.ptr) hipFree(w.ptr);
     if (c->d_tw) hipFree(c->d_tw);
     if (c->d_inv_trn) hipFree(c->d_inv_trn);
@@ -390,6 +329,17 @@ int ofdm_set_stream(ofdm_ctx *c, void *stream) {
     c->stream = (hipStream_t)stream;
     return OFDM_OK;
 }
+int ofdm_use_own_stream(ofdm_ctx *c) {
+    if (!c) return OFDM_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
+    if (c->own_stream) return OFDM_OK;
+    hipStream_t s = nullptr;
+    HIP_TRY(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (c->stream) hipStreamSynchronize(c->stream);
+    c->stream = s;
+    c->own_stream = true;
+    return OFDM_OK;
+}
 int ofdm_synchronize(ofdm_ctx *c) {
     if (!c) return OFDM_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
@@ -433,6 +383,11 @@ int ofdm_set_tuning(ofdm_ctx *c, const char *key, int64_t value) {
         if (std::strcmp(key, k.name) == 0) {
             if (k.profile_only && !kProfile) return OFDM_ERR_UNSUPPORTED; // the ablation branches are not in this build
             if (value < 0 || value > 0x7fffffff) return OFDM_ERR_INVALID;
+            // keys that size LDS tiles or pick template instantiations take only the values their kernels were built for
+            if (k.field == &Tuning::sc_first_lags && value > 1280) return OFDM_ERR_INVALID;       // the first launch's 128-chunk tile holds 1280 samples
+            if (k.field == &Tuning::tx_waves && (value < 1 || value > 32)) return OFDM_ERR_INVALID;
+            if (k.field == &Tuning::demod64_burst && value != 16 && value != 8 && value != 4 && value != 1) return OFDM_ERR_INVALID;
+            if (k.field == &Tuning::sc_wg_per_cu && value > 16) return OFDM_ERR_INVALID;
             c->tune.*(k.field) = (int)value;
             return OFDM_OK;
         }
@@ -629,8 +584,8 @@ static bool sc_make_params(ofdm_ctx *c, const float2 *in, int64_t n_frames, int6
     return true;
 }
 
-static int sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
-                  int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric) {
+int ofdm_abi_sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                    int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric) {
     ScParams p;
     if (!sc_make_params(c, in, n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric, p)) { // no lag fits
         HIP_TRY(c, hipMemsetAsync(d_hat, 0xFF, sizeof(int32_t) * (size_t)n_frames, c->stream));
@@ -692,7 +647,7 @@ int ofdm_sc_correlate_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, 
     if (!n_frames) return OFDM_OK;
     DeviceGuard dev_guard(c->device);
     c->trace.reset();
-    return sc_run(c, reinterpret_cast<const float2 *>(in), n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric);
+    return ofdm_abi_sc_run(c, reinterpret_cast<const float2 *>(in), n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric);
 }
 int ofdm_xcorr_batch(ofdm_ctx *c, const ofdm_fc32 *a, int64_t n_frames, int64_t a_stride, int64_t a_len, const ofdm_fc32 *b,
                      int32_t nb, int32_t *idx_max, float *peak, ofdm_fc32 *out, int64_t out_stride) {
@@ -788,6 +743,7 @@ int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, 
                          const int32_t *payload_len, int32_t payload_bytes, ofdm_fc32 *out, int64_t out_stride) {
     if (!c || n_frames < 0 || payload_bytes < 0 || payload_stride < 0) return OFDM_ERR_INVALID;
     if (n_frames && (!out || (payload_bytes && !payload))) return OFDM_ERR_INVALID;
+    if (n_frames > 1 && payload_stride < payload_bytes) return OFDM_ERR_INVALID; // rows are prefetched for payload_bytes (include/ofdm_hip.h)
     const int64_t frame = ofdm_frame_samples(c, payload_bytes);
     if (out_stride < frame) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
@@ -923,7 +879,7 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         else { c->trace.add("k_freq_corr"); HIP_TRY(c, run_freq_correction(x + 3 * c->S(), n_frames, frame_stride, c->S(), c->S(), fd, c->stream, offs, status)); }
     } else {
     // 1. timing + CFO: Schmidl-Cox over the repeated preamble (replaces xcorr_fft, src/receiver.rs:20-25,39)
-    rc = sc_run(c, x, n_frames, frame_stride, frame_len, n_lags, (int32_t *)w_dhat, fd, metric);
+    rc = ofdm_abi_sc_run(c, x, n_frames, frame_stride, frame_len, n_lags, (int32_t *)w_dhat, fd, metric);
     if (rc) return rc;
     // 2. trimmed start, length check, live symbols (receiver.rs:21-36)
     c->trace.add("k_rx_prepare");
@@ -942,7 +898,7 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         // the kernel also parses the length header, truncates and Hamming-decodes into the caller's rows when they are 4-byte aligned
         bool fin = false;
         hipError_t e = off ? hipErrorNotSupported
-                           : run_rxframe1024(p, nullptr, c->stream, c->num_cu, out, out_stride, out_len, status, c->prm.ecc, &fin);
+                           : run_rxframe1024(p, nullptr, c->stream, c->num_cu, out, out_stride, out_len, c->prm.ecc, &fin);
         if (e == hipSuccess) { fused = true; finished = fin; }
         else if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }

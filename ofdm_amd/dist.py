@@ -17,6 +17,16 @@ def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     return (n_frames * rank) // world, (n_frames * (rank + 1)) // world
 
 
+def lag_ranges(n_samples: int, world: int, L: int, W: int):
+    """The lag ranges [lag_lo, lag_hi) of one capture for `world` ranks: a contiguous split of its n_samples - W - L + 1 lags whose
+    inner cuts are EVEN (a rank's slice then starts on a 16-byte boundary of the fc32 capture, which the LDS-DMA kernels want)."""
+    if world <= 0 or L <= 0 or W <= 0:
+        raise ValueError("bad halo request")
+    valid = max(n_samples - W - L + 1, 0)
+    cuts = [0] + [min(valid, ((valid * r) // world) & ~1) for r in range(1, world)] + [valid]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def halo_ranges(n_samples: int, rank: int, world: int, L: int, W: int) -> Tuple[int, int, int, int, int]:
     """Continuous-capture variant of the split (the reference's caller is examples/jetson_rx.rs:16,48-49,86: one
     decode! per 2 M-sample buffer): the Schmidl-Cox search of ONE long capture over `world` ranks with no exchange.
@@ -26,15 +36,18 @@ def halo_ranges(n_samples: int, rank: int, world: int, L: int, W: int) -> Tuple[
     last own lag is followed by a peak window of W lags -- plus the W + L - 1 samples the last of those
     windows spans.  The overlap of 2 W + L - 1 samples is a read-only halo (overhead, not algorithmic bytes).
 
-    Returns (lag_lo, lag_hi, sample_lo, sample_hi, n_lags): run sc_correlate on samples [sample_lo, sample_hi) with that n_lags;
-    a detection d_hat >= 0 there is the capture's lag lag_lo + d_hat.  merge_first_detection() combines the ranks' answers into
-    exactly what one search over the whole capture returns."""
+    Returns (lag_lo, lag_hi, sample_lo, sample_hi, n_lags): the rank works on samples [sample_lo, sample_hi), whose n_lags lags
+    are its own_lags = lag_hi - lag_lo lags followed by the W lags of overrun.  A rank's answer counts only if its FIRST CROSSING
+    lies among its own lags (a crossing in the overrun belongs to the next rank, which sees that crossing's whole peak window; the
+    window of the overrun is cut off at n_lags): search_own_range() does exactly that with any bounded detector, and
+    ofdm_sc_correlate_long(lag_lo, lag_hi) is that search on the GPU.  merge_first_detection() then takes the lowest rank's answer,
+    which is what one search over the whole capture returns."""
     if world <= 0 or not (0 <= rank < world) or L <= 0 or W <= 0:
         raise ValueError("bad halo request")
     valid = n_samples - W - L + 1
     if valid <= 0:
         return 0, 0, 0, max(n_samples, 0), 0
-    lag_lo, lag_hi = shard_range(valid, rank, world)
+    lag_lo, lag_hi = lag_ranges(n_samples, world, L, W)[rank]
     n_lags = min(lag_hi - lag_lo + W, valid - lag_lo)  # the peak window may run W lags past the own range, never past the capture
     if lag_hi == lag_lo:
         n_lags = 0
@@ -42,12 +55,28 @@ def halo_ranges(n_samples: int, rank: int, world: int, L: int, W: int) -> Tuple[
     return lag_lo, lag_hi, lag_lo, sample_hi, n_lags
 
 
+def search_own_range(search, own_lags: int, n_lags: int):
+    """A rank's part of the split search with any bounded threshold-then-peak detector `search(n_lags) -> (d_hat, f_delta, metric)`
+    over the rank's samples (d_hat < 0: none): first over the OWN lags only -- that decides whether the first crossing is the
+    rank's -- and, if it is, again over own + W lags so that the peak window is whole.  Returns (d_hat, f_delta, metric) relative
+    to the rank's first lag, d_hat = -1 when the rank has no crossing of its own."""
+    if own_lags <= 0 or n_lags <= 0:
+        return -1, 0.0, 0.0
+    d, fd, m = search(min(own_lags, n_lags))
+    if d is None or d < 0:
+        return -1, 0.0, 0.0
+    if n_lags > own_lags:
+        d, fd, m = search(n_lags)
+    return int(d), float(fd), float(m)
+
+
 def merge_first_detection(detections):
-    """detections: per rank, in rank order, (lag_lo, lag_hi, d_hat, f_delta, metric) with d_hat relative to lag_lo (-1 = none).
-    The capture's detection is the one of the LOWEST rank that has any: its first crossing is the capture's first crossing
-    (lower ranks saw none in their own ranges, and a crossing it found in its W-lag overrun is the next rank's first crossing
-    with the same peak window, hence the same answer).  Returns (d_hat, f_delta, metric) with d_hat a lag of the whole capture,
-    or (-1, 0.0, 0.0)."""
+    """detections: per rank, in rank order, (lag_lo, lag_hi, d_hat, f_delta, metric) with d_hat relative to lag_lo (-1 = none),
+    each the result of search_own_range() / ofdm_sc_correlate_long(): a detection whose first crossing lies in [lag_lo, lag_hi).
+    The capture's detection is the one of the LOWEST rank that has any (threshold-then-peak: the first crossing wins, and that
+    rank evaluated its whole peak window).  A d_hat whose crossing may lie in the rank's overrun -- a plain bounded search over
+    own + W lags -- must NOT be passed here: its window is cut off at the end of the rank's samples.  Returns (d_hat, f_delta,
+    metric) with d_hat a lag of the whole capture, or (-1, 0.0, 0.0)."""
     for lag_lo, lag_hi, d_hat, f_delta, metric in detections:
         if d_hat is not None and d_hat >= 0:
             return lag_lo + int(d_hat), float(f_delta), float(metric)
@@ -84,6 +113,10 @@ class Group:
                 kw["device_id"] = torch.device("cuda", self.local)
                 self.device = torch.device("cuda", self.local)
             if not dist.is_initialized():
+                import datetime
+
+                # a bounded wait: a rank that dies between two collectives must end the job with an error, not hang it
+                kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("OFDM_DIST_TIMEOUT_S", "300")))
                 dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
             self.backend = backend

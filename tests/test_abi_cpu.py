@@ -248,3 +248,31 @@ def test_channel_taps_are_the_reference_table(ofdm, orc):
     kat = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")))["channel_taps_8_18"]["taps"]
     np.testing.assert_allclose(taps[8:19], kat, atol=0)
     assert lib.ofdm_channel_taps(None) == -1
+
+
+def test_cpp_sharded_context_partition_arithmetic(tmp_path):
+    """include/ofdm_host.hpp ShardedContext::shard_range (the in-process multi-device split, SURVEY.md 8e) == ofdm_amd.dist.shard_range:
+    contiguous, exhaustive, sizes within one frame.  Compiled with g++ and run without a GPU (nothing but the arithmetic is used)."""
+    import subprocess
+
+    from ofdm_amd.dist import shard_range
+
+    src = tmp_path / "shards.cpp"
+    src.write_text('''#include "ofdm_host.hpp"
+#include <cstdio>
+int main() {
+    for (long n : {0L, 1L, 7L, 8L, 1000L, 1000003L})
+        for (long w : {1L, 2L, 3L, 8L})
+            for (long r = 0; r < w; ++r) { auto p = ofdm::ShardedContext::shard_range(n, r, w); std::printf("%ld %ld %ld %ld %ld\\n", n, w, r, (long)p.first, (long)p.second); }
+    return 0;
+}
+''')
+    exe = tmp_path / "shards"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-L", os.path.join(ROOT, "ofdm_amd"),
+                           "-lofdm_hip", "-Wl,-rpath," + os.path.join(ROOT, "ofdm_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    rows = [tuple(int(v) for v in ln.split()) for ln in out.stdout.splitlines()]
+    assert len(rows) == 6 * (1 + 2 + 3 + 8)
+    for n, w, r, lo, hi in rows:
+        assert (lo, hi) == shard_range(n, r, w)

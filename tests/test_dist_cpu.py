@@ -26,14 +26,37 @@ def test_shard_range_partitions_exactly():
         shard_range(10, 2, 2)
 
 
+def _split_search(orc, cap, world, L, reps):
+    """The `world`-way halo split of one capture with the oracle's bounded detector as every rank's worker."""
+    from ofdm_amd.dist import halo_ranges, merge_first_detection, search_own_range
+
+    n, W = cap.size, reps * L
+    dets, covered = [], 0
+    for r in range(world):
+        lag_lo, lag_hi, s_lo, s_hi, n_lags = halo_ranges(n, r, world, L, W)
+        assert lag_lo == covered and s_lo == lag_lo and s_hi <= n
+        assert r == 0 or lag_lo % 2 == 0                                         # inner cuts are even: 16-byte aligned slices
+        covered = lag_hi
+        assert s_hi - s_lo <= (lag_hi - lag_lo) + 2 * W + L - 1                  # own lags + the halo, never more
+
+        def search(k, lo=s_lo, hi=s_hi):
+            d, _, m, fd = orc.sc_sync(cap[lo:hi], L=L, window_reps=reps, n_lags=k, threshold=0.5)
+            return d, fd, m
+
+        dets.append((lag_lo, lag_hi) + search_own_range(search, lag_hi - lag_lo, n_lags))
+    assert covered == max(n - W - L + 1, 0)
+    return merge_first_detection(dets)
+
+
 def test_halo_split_of_a_long_capture_equals_the_whole_search(orc):
     """SURVEY.md 8(e), continuous-stream variant (the reference's caller: examples/jetson_rx.rs:16,48-49,86, one decode! per
     long buffer): the Schmidl-Cox search of ONE capture split over `world` ranks by lag range with a read-only halo of
-    2 W + L - 1 samples and no exchange.  Per shard the worker is the oracle's sc_sync on the shard's samples with the shard's
-    n_lags; the merged detection must be exactly the whole capture's -- for a two-frame capture, a frame that straddles a shard
-    boundary, a crossing in the last lags of a shard (peak in the next one's range), and a noise-only capture."""
+    2 W + L - 1 samples and no exchange.  Per shard the worker is the oracle's sc_sync through dist.search_own_range (own lags
+    first, the whole window only for a crossing among them); the merged detection must be exactly the whole capture's -- for a
+    two-frame capture, a frame that straddles a shard boundary, a crossing in the last lags of a shard (peak in the next one's
+    range), and a noise-only capture."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from ofdm_amd.dist import halo_ranges, merge_first_detection
+    from ofdm_amd.dist import halo_ranges
     from util import through_channel
 
     L, reps = 80, 3
@@ -52,25 +75,45 @@ def test_halo_split_of_a_long_capture_equals_the_whole_search(orc):
         want_d, _, want_m, want_fd = orc.sc_sync(cap, L=L, window_reps=reps, n_lags=0, threshold=0.5)
         assert (want_d >= 0) == bool(starts), case
         for world in (1, 2, 3, 4, 7):
-            dets, covered = [], 0
-            for r in range(world):
-                lag_lo, lag_hi, s_lo, s_hi, n_lags = halo_ranges(n, r, world, L, W)
-                assert lag_lo == covered and s_lo == lag_lo and s_hi <= n
-                covered = lag_hi
-                assert s_hi - s_lo <= (lag_hi - lag_lo) + 2 * W + L - 1          # own lags + the halo, never more
-                if n_lags == 0:
-                    dets.append((lag_lo, lag_hi, -1, 0.0, 0.0))
-                    continue
-                d, _, m, fd = orc.sc_sync(cap[s_lo:s_hi], L=L, window_reps=reps, n_lags=n_lags, threshold=0.5)
-                dets.append((lag_lo, lag_hi, d, fd, m))
-            assert covered == n - W - L + 1
-            got_d, got_fd, got_m = merge_first_detection(dets)
+            got_d, got_fd, got_m = _split_search(orc, cap, world, L, reps)
             assert got_d == want_d, (case, world, got_d, want_d)
             if want_d >= 0:
                 assert abs(got_fd - want_fd) <= 1e-12 and abs(got_m - want_m) <= 1e-12, (case, world)
     assert halo_ranges(100, 0, 2, 80, 240) == (0, 0, 0, 100, 0)                   # no lag fits: nothing to search
     with pytest.raises(ValueError):
         halo_ranges(1000, 2, 2, 80, 240)
+
+
+def test_halo_split_with_the_crossing_swept_across_a_cut(orc):
+    """The case round 3's merge got wrong: a rank whose FIRST crossing falls into its W-lag overrun sees that
+    crossing's peak window cut off at the end of its samples, so its answer must not win.  The frame start is swept in steps of
+    20 samples so that the crossing moves from W + L lags before a cut to W lags behind it, for two- and four-way splits."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ofdm_amd.dist import lag_ranges
+    from util import through_channel
+
+    L, reps = 80, 3
+    W = reps * L
+    rng = np.random.default_rng(77)
+    tx = orc.encode(bytes(rng.integers(0, 256, 300, dtype=np.uint8)), True, orc.QAM64, 64)
+    n = 9000
+    noise = 0.004 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    overrun = 0
+    for world in (2, 4):
+        cut = lag_ranges(n, world, L, W)[world // 2 - 1][1]                      # the cut nearest the middle of the capture
+        for st in range(cut - W - 2 * L, cut + W, 20):                          # the crossing follows the frame start by ~L + 10 lags
+            cap = through_channel(orc, rng, tx, n, st, 0.004, snr_db=None, data_start=800).astype(np.complex128) + noise
+            cap = cap.astype(np.complex64).astype(np.complex128)
+            want_d, _, want_m, want_fd = orc.sc_sync(cap, L=L, window_reps=reps, n_lags=0, threshold=0.5)
+            assert want_d >= 0
+            got_d, got_fd, got_m = _split_search(orc, cap, world, L, reps)
+            assert got_d == want_d, (world, st, cut, got_d, want_d)
+            assert abs(got_fd - want_fd) <= 1e-12 and abs(got_m - want_m) <= 1e-12
+            # how often the old rule (lowest rank with ANY detection over own + W lags) would have been wrong here
+            lo, hi = lag_ranges(n, world, L, W)[world // 2 - 1]
+            d_old, _, _, _ = orc.sc_sync(cap[lo:min(n, hi + 2 * W + L - 1)], L=L, window_reps=reps, n_lags=hi - lo + W, threshold=0.5)
+            overrun += d_old >= 0 and lo + d_old != want_d
+    assert overrun > 0                                                            # the sweep does reach the case
 
 
 class _FakeCtx:
@@ -121,6 +164,53 @@ def test_config_block_timing_is_max_over_ranks():
         p.join(60)
         assert p.exitcode == 0
     assert len(per_rank) == 2 and ms == max(per_rank) and per_rank[1] > per_rank[0] and per_rank[0] >= 9.0 and r == 0
+
+
+def _failing_timing_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from ofdm_amd.dist import Group
+    from tools import rank_timing
+
+    g = Group(backend="gloo")
+    calls = [0]
+
+    def fn():
+        calls[0] += 1
+        if rank == 1 and calls[0] == 2:   # the warm-up passes, the first timed step dies on rank 1 only
+            raise ValueError("boom on rank 1")
+        return rank
+
+    try:
+        rank_timing.timed(_FakeCtx(), _FakeTorch, fn, 3, g)
+        q.put((rank, "no error"))
+    except ValueError as e:
+        q.put((rank, "own: " + str(e)))
+    except rank_timing.RankFailed as e:
+        q.put((rank, "peer: " + str(e)[:40]))
+    (n,) = g.reduce_sum(1.0)              # the ranks are still in step: the next collective matches
+    q.put((rank, f"after: {int(n)}"))
+    g.close()
+
+
+def test_config_block_timing_survives_a_failing_rank():
+    """a rank that raises inside a timed block must not leave its peers in a mismatched collective.  timed() catches the
+    error, still takes part in the region's barrier / gather (NaN for its time) and raises afterwards; the healthy rank raises
+    RankFailed; both reach the block's closing reduction."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_failing_timing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(4))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][0] == 0 and got[0][1].startswith("after: 2") or got[1][1].startswith("after: 2")
+    msgs = {(r, m.split(":")[0]) for r, m in got}
+    assert msgs == {(0, "peer"), (0, "after"), (1, "own"), (1, "after")}, got
 
 
 def _worker(rank, world, port, q):

@@ -445,6 +445,27 @@ def test_sc_correlate_two_launch_search_equals_the_whole_search(api, orc, reps):
     assert int((res[0]["status"][:20] == 0).sum()) >= 18
 
 
+def test_sc_first_lags_at_the_edge_of_the_first_tile(api, orc):
+    """with sc_first_lags in 949 .. 1280 the first launch's stage (first + W + L + 11 samples) would not fit its
+    128-chunk tile of 1280 samples; such values take the single-launch search, the largest that fits (948 for W = 240) is clamped
+    to the tile, values above 1280 are refused -- and every accepted value gives the whole search's results."""
+    rng = np.random.default_rng(949)
+    tx = orc.encode(bytes(rng.integers(0, 256, 560, dtype=np.uint8)), True, orc.QAM64)
+    span = 2560
+    caps = np.stack([through_channel(orc, rng, tx, span, d, 0.01, 30.0) for d in (5, 380, 600, 640, 700, 410)])
+    want = [orc.sc_sync(wide(c), 80, 3, 0, 0.5) for c in caps]
+    for first, kernel in ((948, "k_sc_cf<128,first>"), (949, "k_sc_cf<256>"), (955, "k_sc_cf<256>"), (1280, "k_sc_cf<256>")):
+        ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning={"sc_first_lags": first})
+        d, fd, m = ctx.sc_correlate(dev(ctx, caps))
+        assert kernel in ctx.last_dispatch(), (first, ctx.last_dispatch())
+        for f, (wd, _, wm, wfd) in enumerate(want):
+            assert int(host(d)[f]) == wd and abs(float(host(fd)[f]) - wfd) <= 1e-9, (first, f)
+    ctx = api.Context(modulation=api.QAM64, guard_bands=True)
+    for key, bad in (("sc_first_lags", 1281), ("tx_waves", 0), ("tx_waves", 33), ("demod64_burst", 5), ("sc_wg_per_cu", 17)):
+        with pytest.raises(api.OfdmError):
+            ctx.set_tuning(key, bad)
+
+
 def test_sc_correlate_untrusted_f32_filter(api, orc):
     # A strong burst ahead of the frame makes the prefix energy >> window energy, so the fast kernel's f32 filter must
     # not be trusted there: those frames are redone by the all-f64 kernel (device-side slow list).  Results still exact.
@@ -1630,6 +1651,11 @@ def test_cpp_host_loopback(ofdm):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, (args, r.stdout, r.stderr)          # exit 0 <=> Analysis.num_errs == 0
         assert "num_errs: 0" in r.stdout and "I met a traveller" in r.stdout
+    # frame-index split inside one process: N contexts (own stream, own host thread) == one context, byte for byte
+    for n_ctx in (1, 2, 3):
+        r = subprocess.run([exe, "--devices", str(n_ctx), "--frames", "37", "--guard", "--qam64", "--bytes", "560", "--timing-error"],
+                           capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0 and "identical to the single-context result" in r.stdout and "37 decoded, num_errs: 0" in r.stdout, (n_ctx, r.stdout, r.stderr)
     # fc32 file wire format + capture slicing (examples/lab3c.rs:15-54, src/utils.rs:228-254)
     import tempfile
     import numpy as np

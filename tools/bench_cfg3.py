@@ -19,9 +19,15 @@ SPAN = 2176      # slot: 2080-sample frame + delay <= 64 + channel tail, a multi
 NBYTES = 560     # 16 data symbols of 36 B minus the 16-byte length header
 
 
-def synth(api, torch, ctx, n_frames, span=SPAN, snr_db=30.0, seed=3):
+LATE_SPAN = 2560   # late-packet layout: the largest slot the one-tile kernel holds; the frame may start anywhere it still fits
+LATE_NOISE_ONLY = 0.10
+
+
+def synth(api, torch, ctx, n_frames, span=SPAN, snr_db=30.0, seed=3, max_delay=64, noise_only=0.0):
     """[n_frames, span] captures + payloads.  TX by the library, channel by the library's GPU restatement of
-    src/channel.rs (FIR CHANNEL, CFO, noise) with the test-bench extensions: per-frame delay, signed CFO."""
+    src/channel.rs (FIR CHANNEL, CFO, noise) with the test-bench extensions: per-frame delay, signed CFO.
+    max_delay: delays are uniform over [1, max_delay]; noise_only: that share of the slots holds no packet at all (noise of the
+    packets' own level) -- the placements an early-exit search cannot decide early."""
     g = torch.Generator(device=ctx.device)
     g.manual_seed(seed)
     x = torch.empty((n_frames, span), dtype=torch.complex64, device=ctx.device)
@@ -30,9 +36,19 @@ def synth(api, torch, ctx, n_frames, span=SPAN, snr_db=30.0, seed=3):
     for lo in range(0, n_frames, chunk):
         hi = min(lo + chunk, n_frames)
         tx = ctx.encode_batch(payload[lo:hi].contiguous())  # [m, 2080]
-        d = torch.randint(1, 65, (hi - lo,), device=ctx.device, generator=g, dtype=torch.int32)
+        d = torch.randint(1, max_delay + 1, (hi - lo,), device=ctx.device, generator=g, dtype=torch.int32)
         fd = (torch.rand((hi - lo,), device=ctx.device, generator=g, dtype=torch.float64) * 1.9 - 0.95) * math.pi / ctx.S
         ctx.channel_batch(tx, snr_db=snr_db, seed=seed * 1_000_003 + lo, delay=d, f_delta=fd, out=x[lo:hi])
+        if noise_only > 0:
+            empty = torch.rand((hi - lo,), device=ctx.device, generator=g) < noise_only
+            k = int(empty.sum())
+            if k:
+                # the packets' own noise floor, from the first sample of every slot (always in front of the packet: delay >= 1);
+                # channel.rs draws U(-1, 1) s per component: mean |.| = 0.765 s, same power as a Gaussian of s / sqrt(3)
+                sigma = float(x[lo:hi, 0].abs().mean()) * 0.755
+                nz = torch.randn((k, span, 2), dtype=torch.float32, device=ctx.device, generator=g) * sigma
+                x[lo:hi][empty] = torch.view_as_complex(nz)
+                del nz
         del tx
     torch.cuda.synchronize()
     return x, payload
@@ -49,6 +65,14 @@ def _ber(torch, res, payload):
     diff = torch.bitwise_xor(res["bytes"][:, :NBYTES], payload)[ok]
     bits = sum(int(((diff >> sh) & 1).sum()) for sh in range(8))
     return nok, bits / max(1, nok * NBYTES * 8)
+
+
+def required_sync_bytes(torch, d_hat, span, W, L):
+    """The samples ANY threshold-then-peak detector has to read, in bytes: every lag up to the reported peak d_hat must have been
+    evaluated, and the last of them spans W + L samples -- the whole slot where nothing is found.  (A lower bound: the peak window
+    really runs to d1 + W >= d_hat.)  This, not the slot size, is what an early-exit search is measured against."""
+    need = torch.where(d_hat >= 0, torch.clamp(d_hat.to(torch.int64) + (W + L), max=span), torch.full_like(d_hat, span, dtype=torch.int64))
+    return int(need.sum()) * 8
 
 
 def cpu_leg(x, payload, gpu, D, n_sample, threads):
@@ -95,6 +119,97 @@ def cpu_leg(x, payload, gpu, D, n_sample, threads):
             "cpu_ber_on_sample": cpu_bits / max(1, cpu_ok * NBYTES * 8)}
 
 
+def _roof(bytes_, ms, **extra):
+    gbs = bytes_ / (ms / 1e3) / 1e9
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, **extra}
+
+
+def _traffic(kernels):
+    """HBM bytes per frame of the named kernels from the newest committed PMC pass (tools/pmc_traffic.py), or None."""
+    import json
+    for rnd in ("r04", "r03"):
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{rnd}_pmc_traffic.json")
+        try:
+            pm = json.load(open(path))
+            tot = 0.0
+            for k in kernels:
+                tot += pm[k]["read_bytes_per_frame"] + pm[k].get("write_bytes_per_frame", 0.0)
+            return tot, f"profiles/{rnd}_pmc_traffic.json (separate --pmc passes of tools/pmc_traffic.py, not measured in this run)"
+        except Exception:
+            continue
+    return None, None
+
+
+def chain_block(api, torch, ctx, x, payload, n_frames, steps, grp, W_, name_suffix="", one_pass=True, span=SPAN, traffic_keys=None):
+    """The full RX chain over one data set: every lag, bounded, one-pass kernel; Schmidl-Cox alone (every lag computed; the product's
+    two-launch early-exit search).  Every early-exit block carries TWO figures: `capture_throughput` (slot bytes / time: what a user
+    sees, NOT a roofline -- an early exit skips bytes) and `roofline` (bytes the decision REQUIRES / time)."""
+    out = {}
+    D = ctx.data_symbols(NBYTES)
+    L, Wn = ctx.S, ctx.params.sync_window_reps * ctx.S
+    slot_bytes = n_frames * (span * 8 + NBYTES)
+    ctx.set_tuning("one_pass_rx", 0)
+    d_all, _, _ = ctx.sc_correlate(x)
+    sync_req = required_sync_bytes(torch, d_all, span, Wn, L)
+    found = int((d_all >= 0).sum())
+    # receive body: the (5 + D) N useful samples of every frame found (CP never needed) + the decoded payload
+    chain_req = sync_req + found * ((5 + D) * ctx.n_fft * 8 + NBYTES)
+    out["required_bytes"] = {"sync_per_frame": sync_req / n_frames, "chain_per_frame": chain_req / n_frames, "slot_per_frame": span * 8,
+                             "frames_with_a_detection": found,
+                             "definition": "sync: 8 B x min(slot, d_hat + W + L) per slot (the whole slot when nothing is found) -- what any "
+                                           "threshold-then-peak detector must read; chain: + (5 + D) N useful samples and the payload of every "
+                                           "frame found"}
+
+    def leg(name, lags, one):
+        ctx.set_tuning("one_pass_rx", int(one))
+        try:
+            ms, per_rank, r = _timed(ctx, torch, lambda: ctx.decode_batch(x, max_symbols=D, n_lags=lags), steps, grp)
+        finally:
+            ctx.set_tuning("one_pass_rx", 0)
+        early_exit = not one and lags == 0          # the two-launch search stops reading a slot once its decision is determined
+        bytes_ = chain_req if early_exit else slot_bytes
+        tr, src = _traffic(traffic_keys) if (traffic_keys and early_exit) else (None, None)
+        out[name + name_suffix] = {
+            "ms": ms, "ms_per_rank": per_rank, "msamples_per_s": W_ * n_frames * span / ms / 1e3, "hbm_passes": 1 if one else 2,
+            "dispatch": ctx.last_dispatch(),
+            "capture_throughput": {"gb_per_s": slot_bytes / (ms / 1e3) / 1e9, "of_hbm_peak": slot_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "slot bytes / time; not a roofline when the search exits early"},
+            "roofline": _roof(bytes_, ms, per="GPU (slowest rank)", algorithmic_bytes_per_launch=bytes_,
+                              bytes="required (see required_bytes)" if early_exit else "the whole slot once + payload",
+                              traffic=None if tr is None else tr * n_frames, traffic_source=src,
+                              kernels="k_sc_cf<256,2,3,6,true> (one pass)" if one else
+                                      "k_sc_cf<128,2,4,0> over the first lags + k_sc_cf<256,2,4,0> over the frames they do not determine (bounded: "
+                                      "k_sc_cf<128,2,4,0> alone) + k_sc_post + k_sc_tile<list> + k_rx_prepare + k_rxframe64<6,true> (finish fused); see dispatch")}
+        return r
+
+    full = leg("full_chain_all_lags", 0, False)
+    res = {"full": full}
+    if one_pass:
+        res["bounded"] = leg("full_chain_bounded_256_lags", SYNC_LAGS, False)
+        res["one"] = leg("full_chain_all_lags_one_pass_kernel", 0, True)
+    # --- Schmidl-Cox alone over every lag of every slot: (a) the kernel that COMPUTES every lag (one launch, tuning sc_first_lags = 0:
+    #     the north-star kernel against the HBM roofline, bytes = the whole slot, which it does read), (b) the product path: the first
+    #     384 lags decide every frame whose crossing and peak window lie among them, the rest take the whole search (same results)
+    sc_slot = n_frames * (span * 8 + 16)
+    first = ctx.get_tuning("sc_first_lags")
+    for name, fl in (("schmidl_cox", 0), ("schmidl_cox_two_launches", first)):
+        ctx.set_tuning("sc_first_lags", fl)
+        try:
+            sms, _, _ = _timed(ctx, torch, lambda: ctx.sc_correlate(x), steps, grp)
+            disp = ctx.last_dispatch()
+        finally:
+            ctx.set_tuning("sc_first_lags", first)
+        bytes_ = sc_slot if fl == 0 else sync_req + 16 * n_frames
+        out[name + name_suffix] = {
+            "kernel": disp + (f" (all {span - Wn - L + 1} lags of every {span}-sample slot computed)" if fl == 0 else
+                              f" (first {fl} lags, then the whole search for the frames they do not determine)"),
+            "kernel_ms": sms, "msamples_per_s": W_ * n_frames * span / sms / 1e3,
+            "capture_throughput": {"gb_per_s": sc_slot / (sms / 1e3) / 1e9, "of_hbm_peak": sc_slot / (sms / 1e3) / 1e9 / HBM_PEAK_GBS},
+            "roofline": _roof(bytes_, sms, algorithmic_bytes_per_launch=bytes_,
+                              bytes="the whole slot (every lag is computed)" if fl == 0 else "required (see required_bytes)")}
+    return out, res
+
+
 def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
     """grp (ofdm_amd.dist.Group, optional): every rank decodes its OWN n_frames captures (weak scaling, no data-path
     collective); times are the max over ranks, rates the aggregate over all ranks."""
@@ -103,34 +218,18 @@ def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
     ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True, device=device)
     x, payload = synth(api, torch, ctx, n_frames, seed=3 + rank)
     D = ctx.data_symbols(NBYTES)
-    chain_bytes = n_frames * (SPAN * 8 + NBYTES)  # algorithmic: the capture once + the decoded payload
     out = {"workload": "cfg3: 2080-sample 64QAM frames at stride 2176, delay 1..64, CFO +-0.95 pi/80, FIR CHANNEL, 30 dB noise "
                        "(channel_batch = src/channel.rs:33-74 on the GPU)", "frames": n_frames, "n_gpus": W,
-           "frames_per_gpu": n_frames}
-
-    ctx.set_tuning("one_pass_rx", 0)
-
-    def leg(name, lags, one_pass):
-        ctx.set_tuning("one_pass_rx", int(one_pass))
-        try:
-            ms, per_rank, r = _timed(ctx, torch, lambda: ctx.decode_batch(x, max_symbols=D, n_lags=lags), steps, grp)
-        finally:
-            ctx.set_tuning("one_pass_rx", 0)
-        out[name] = {"ms": ms, "ms_per_rank": per_rank, "msamples_per_s": W * n_frames * SPAN / ms / 1e3, "hbm_passes": 1 if one_pass else 2,
-                     "dispatch": ctx.last_dispatch(),
-                     "roofline": {"bound": "hbm", "achieved": chain_bytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": chain_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "per": "GPU (slowest rank)",
-                                  "algorithmic_bytes_per_launch": chain_bytes,
-                                  "kernels": "k_sc_cf<256,2,3,6,true> (one pass)" if one_pass else
-                                             "k_sc_cf<128,2,4,0> (one wavefront per frame) over the first lags + k_sc_cf<256,2,4,0> over the frames they do not determine (bounded: k_sc_cf<128,2,4,0> alone) + k_sc_post + k_sc_tile<list> + k_rx_prepare + k_rxframe64<6,true> (finish fused); see dispatch"}}
-        return r
-
-    full = leg("full_chain_all_lags", 0, False)
+           "frames_per_gpu": n_frames,
+           "parity": "64-QAM and the Schmidl-Cox detector are north-star extensions the reference lacks (EXT-1, EXT-3): parity unpinned by "
+                     "the reference, the oracle is the definition"}
+    blocks, res = chain_block(api, torch, ctx, x, payload, n_frames, steps, grp, W,
+                              traffic_keys=("staged_first_lags_k_sc_cf_128", "k_rxframe64"))
+    out.update(blocks)
+    full, bounded, one = res["full"], res["bounded"], res["one"]
     nok, ber = _ber(torch, full, payload)  # this rank's frames (rank 0's in the report)
     out["frames_decoded"] = nok
     out["ber_decoded_frames_vs_tx_payload"] = ber
-    bounded = leg("full_chain_bounded_256_lags", SYNC_LAGS, False)
-    one = leg("full_chain_all_lags_one_pass_kernel", 0, True)
     both = (full["status"] == 0) & (bounded["status"] == 0)
     out["bounded_vs_full_search"] = {
         "frames_ok_in_both_but_different": int(((full["offset"] != bounded["offset"]) | (full["len"] != bounded["len"])
@@ -148,32 +247,23 @@ def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
         threads = cb.host_threads()
         out["cpu_baseline"] = cpu_leg(x, payload, full, D, min(n_frames, 65536, 1024 * threads), threads)
         out["speedup_vs_cpu"] = out["full_chain_all_lags"]["msamples_per_s"] / out["cpu_baseline"]["value"]
-    del full, bounded, one
+    del full, bounded, one, res
     # --- TX side of the hot path: encode (modulate + encode_block + IFFT + CP + header + normalise) for the same payloads
     npay = min(n_frames, 262144)
     txo = ctx.encode_batch(payload[:npay])
     tms, _, _ = _timed(ctx, torch, lambda: ctx.encode_batch(payload[:npay], out=txo), steps, grp)
     tx_bytes = npay * (txo.shape[-1] * 8 + NBYTES)
     out["tx_encode"] = {"kernel": "k_txframe64<6, true>", "frames": npay, "ms": tms, "msamples_per_s": W * npay * txo.shape[-1] / tms / 1e3,
-                        "roofline": {"bound": "hbm", "achieved": tx_bytes / (tms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": tx_bytes / (tms / 1e3) / 1e9 / HBM_PEAK_GBS}}
-    del txo
-    # --- Schmidl-Cox alone over every lag of every slot: (a) the kernel that COMPUTES every lag (one launch, tuning sc_first_lags = 0:
-    #     the north-star kernel against the HBM roofline), (b) the product path: the first 384 lags decide every frame whose crossing and
-    #     peak window lie among them, the rest take the whole search (same results; it reads a third of the slot when the packet is early)
-    sc_bytes = n_frames * (SPAN * 8 + 16)
-    first = ctx.get_tuning("sc_first_lags")
-    for name, fl in (("schmidl_cox", 0), ("schmidl_cox_two_launches", first)):
-        ctx.set_tuning("sc_first_lags", fl)
-        try:
-            sms, _, _ = _timed(ctx, torch, lambda: ctx.sc_correlate(x), steps, grp)
-            disp = ctx.last_dispatch()
-        finally:
-            ctx.set_tuning("sc_first_lags", first)
-        out[name] = {"kernel": disp + (" (all 1857 lags of every 2176-sample slot computed)" if fl == 0 else
-                                       f" (first {fl} lags, then the whole search for the frames they do not determine)"),
-                     "kernel_ms": sms, "msamples_per_s": W * n_frames * SPAN / sms / 1e3,
-                     "roofline": {"bound": "hbm", "achieved": sc_bytes / (sms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": sc_bytes / (sms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                  "algorithmic_bytes_per_launch": sc_bytes}}
+                        "roofline": _roof(tx_bytes, tms)}
+    del txo, x, payload
+    torch.cuda.empty_cache()
+    # --- the placements an early exit cannot decide early: delay uniform over the whole slack of a 2560-sample slot
+    #     (half of the crossings beyond the first launch's reach) and 10 % of the slots without a packet
+    late_delay = LATE_SPAN - 2080 - 63
+    xl, pl = synth(api, torch, ctx, n_frames, span=LATE_SPAN, seed=31 + rank, max_delay=late_delay, noise_only=LATE_NOISE_ONLY)
+    lblocks, lres = chain_block(api, torch, ctx, xl, pl, n_frames, steps, grp, W, name_suffix="_late_packets", one_pass=False, span=LATE_SPAN)
+    nok_l, ber_l = _ber(torch, lres["full"], pl)
+    out["late_packets"] = {"workload": f"the same frames in {LATE_SPAN}-sample slots, delay uniform over 1..{late_delay}, "
+                                       f"{int(LATE_NOISE_ONLY * 100)} % of the slots noise only",
+                           "frames_decoded": nok_l, "ber_decoded_frames_vs_tx_payload": ber_l, **lblocks}
     return out

@@ -70,6 +70,7 @@ int main(int argc, char **argv) {
     ModulationScheme modulation = ModulationScheme::Qpsk;
     const char *tx_file = nullptr, *rx_file = nullptr; // examples/lab3c.rs: --transmit f / --receive f [--start a --stop b]
     long start = 0, stop = -1;
+    int devices = 0; long frames = 0; // --devices N --frames F: F frames through N contexts side by side (ShardedContext)
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--timing-error")) timing_error = true;          // lab3b
         else if (!std::strcmp(argv[i], "--guard")) guard_bands = true;
@@ -81,6 +82,8 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(argv[i], "--receive") && i + 1 < argc) rx_file = argv[++i];
         else if (!std::strcmp(argv[i], "--start") && i + 1 < argc) start = std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "--stop") && i + 1 < argc) stop = std::atol(argv[++i]);
+        else if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "--pilots") && i + 1 < argc)                 // "stdrng": the reference's own tables (restated)
             default_pilot_choice() = !std::strcmp(argv[++i], "stdrng") ? Pilots::StdRng : Pilots::Default;
     }
@@ -96,6 +99,47 @@ int main(int argc, char **argv) {
             plain->resize(std::min(plain->size(), text.size()));
             return *plain;
         };
+        if (devices > 0) {
+            // Frame-index split inside one process: F frames with different payloads, encoded and decoded by N contexts
+            // (context r on GPU r mod the visible count, each with its own stream and host thread); the result must equal the
+            // single-context result byte for byte.
+            if (frames <= 0) frames = 64;
+            int ngpu = 0;
+            check(ofdm_device_count(&ngpu), "ofdm_device_count");
+            std::vector<int> devs;
+            for (int r = 0; r < devices; ++r) devs.push_back(r % std::max(ngpu, 1));
+            std::vector<uint8_t> pay((size_t)frames * num_bytes);
+            for (long f = 0; f < frames; ++f)
+                for (size_t i = 0; i < num_bytes; ++i) pay[(size_t)f * num_bytes + i] = (uint8_t)corpus[(i + 7 * (size_t)f) % std::strlen(corpus)];
+            ShardedContext sh(devs, guard_bands, modulation);
+            Context one(guard_bands, modulation);
+            const auto tx_sh = sh.encode_batch(pay.data(), frames, (int32_t)num_bytes, 5);
+            const auto tx_one = one.encode_batch(pay.data(), frames, (int32_t)num_bytes);
+            if (tx_sh.size() != tx_one.size() || std::memcmp(tx_sh.data(), tx_one.data(), tx_one.size() * sizeof(ofdm_fc32))) { std::printf("sharded encode differs\n"); return 5; }
+            const int64_t flen = (int64_t)(tx_one.size() / (size_t)frames), stride = (flen + 63 + 64 + 1) & ~(int64_t)1;
+            std::vector<ofdm_fc32> cap((size_t)(frames * stride));
+            for (long f = 0; f < frames; ++f) { // channel per frame, a different delay and CFO draw for each
+                std::vector<ofdm_fc32> one_tx(tx_one.begin() + f * flen, tx_one.begin() + (f + 1) * flen);
+                auto rx = channel(Context::from_fc32(one_tx), 30.0, timing_error, 2021 + (uint64_t)f, nullptr);
+                const auto fc = Context::to_fc32(rx);
+                const size_t delay = (size_t)(f * 13 % 60);
+                for (size_t i = 0; i < fc.size() && delay + i < (size_t)stride; ++i) cap[(size_t)(f * stride) + delay + i] = fc[i];
+            }
+            const int32_t D = (int32_t)ofdm_data_symbols(one.raw(), (int64_t)num_bytes);
+            const auto r_sh = sh.decode_batch(cap.data(), frames, stride, stride, D, 0, 3);
+            const auto r_one = one.decode_batch(cap.data(), frames, stride, stride, D);
+            if (r_sh.len != r_one.len || r_sh.status != r_one.status || r_sh.offset != r_one.offset || r_sh.bytes != r_one.bytes) { std::printf("sharded decode differs\n"); return 5; }
+            uint32_t errs = 0; long ok = 0;
+            for (long f = 0; f < frames; ++f) {
+                if (r_sh.status[(size_t)f] != OFDM_FRAME_OK || r_sh.len[(size_t)f] != (int32_t)num_bytes) continue;
+                std::vector<uint8_t> got(r_sh.bytes.begin() + f * r_sh.row, r_sh.bytes.begin() + f * r_sh.row + (long)num_bytes);
+                std::vector<uint8_t> want(pay.begin() + f * (long)num_bytes, pay.begin() + (f + 1) * (long)num_bytes);
+                errs += Analysis(want, got).num_errs; ++ok;
+            }
+            std::printf("sharded over %d contexts on %d GPU(s): %ld frames, identical to the single-context result; %ld decoded, num_errs: %u\n",
+                        devices, std::max(ngpu, 1), frames, ok, errs);
+            return ok == frames && errs == 0 ? 0 : 1;
+        }
         if (rx_file) { // decode a stored capture (or a slice of it)
             std::vector<Complex64> cap;
             if (!read_fc32(rx_file, cap, start, stop)) { std::printf("cannot read %s\n", rx_file); return 4; }
