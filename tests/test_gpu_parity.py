@@ -451,8 +451,8 @@ def test_sc_first_lags_at_the_edge_of_the_first_tile(api, orc):
     to the tile, values above 1280 are refused -- and every accepted value gives the whole search's results."""
     rng = np.random.default_rng(949)
     tx = orc.encode(bytes(rng.integers(0, 256, 560, dtype=np.uint8)), True, orc.QAM64)
-    span = 2560
-    caps = np.stack([through_channel(orc, rng, tx, span, d, 0.01, 30.0) for d in (5, 380, 600, 640, 700, 410)])
+    span = 2544   # 2225 lags: the most a one-tile search holds is 2240 (256 chunks - W - L)
+    caps = np.stack([through_channel(orc, rng, tx, span, d, 0.01, 30.0) for d in (5, 380, 400, 330, 270, 410)])
     want = [orc.sc_sync(wide(c), 80, 3, 0, 0.5) for c in caps]
     for first, kernel in ((948, "k_sc_cf<128,first>"), (949, "k_sc_cf<256>"), (955, "k_sc_cf<256>"), (1280, "k_sc_cf<256>")):
         ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning={"sc_first_lags": first})

@@ -19,7 +19,7 @@ SPAN = 2176      # slot: 2080-sample frame + delay <= 64 + channel tail, a multi
 NBYTES = 560     # 16 data symbols of 36 B minus the 16-byte length header
 
 
-LATE_SPAN = 2560   # late-packet layout: the largest slot the one-tile kernel holds; the frame may start anywhere it still fits
+LATE_SPAN = 2544   # late-packet layout: about the largest slot whose every lag the one-tile kernel holds (2225 of at most 2240); the frame may start anywhere it still fits
 LATE_NOISE_ONLY = 0.10
 
 
