@@ -231,6 +231,7 @@ int sc_tile_lags() { return SC_CH; }
 //     all-f64 kernel k_sc_tile.  Outputs equal the f64 oracle's.
 constexpr float SC_EPS = 1e-3f;         // relative guard band of the f32 filter around the threshold / the maximum
 constexpr float SC_UNSAFE_RATIO = 20.f; // prefix energy / window energy above which a lag is never trusted
+constexpr float SC_PREFIX_ERR = 1.6e-5f; // bound on |f32 window sum - exact| / prefix magnitude (the scans and slides stay below 4e-6; x 4 for margin)
 constexpr int SC_MAXCAND = 4;
 
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_d(double x) {
@@ -631,13 +632,25 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                         mmax = fmaxf(mmax, mp[k]);
                     }
                     unsafe_t = etop > SC_UNSAFE_RATIO * emin; // emin stays huge when no lag has energy
-                    if (unsafe_t || mmax >= p.thr_lo) {
+                    // An untrusted lag is not yet a possible crossing.  In front of a late packet the window holds noise while the
+                    // prefixes behind it already carry packet energy (ratios of 10^3 .. 10^4): the sums are too coarse to place the
+                    // metric within SC_EPS, but not too coarse to prove it far below the threshold.  Every sum is off by at most
+                    // SC_PREFIX_ERR x the prefix magnitude, i.e. by er = SC_PREFIX_ERR etop / emin relative to the smallest window
+                    // energy, so M <= (sqrt(M_f32) + er)^2 / (1 - er)^2; lags that stay below the threshold under that bound cannot
+                    // cross (without this every frame whose packet starts more than W samples into its slot went to the slow list).
+                    bool maybe = unsafe_t;
+                    if (unsafe_t && mmax >= 0.f) {
+                        const float er = SC_PREFIX_ERR * etop * __builtin_amdgcn_rcpf(emin);
+                        const float up = __builtin_amdgcn_sqrtf(mmax) + 1.5f * er, dn = 1.f - er; // |P| is off by up to sqrt(2) such errors
+                        maybe = !(er < 0.25f && up * up < p.thr_lo * dn * dn);
+                    }
+                    if (maybe || mmax >= p.thr_lo) {
 #pragma unroll
                         for (int k = 0; k < 5; ++k) {
                             const int kk = hh ? k : 4 - k;           // visit this lane's lags in decreasing order
                             const int lag = hh ? m0 + 9 - kk : m0 + kk;
                             const float m = mp[kk];
-                            if (m >= 0.f && (unsafe_t || m >= p.thr_lo)) lo = lag;
+                            if (m >= 0.f && (maybe || m >= p.thr_lo)) lo = lag;
                             if (m >= 0.f && !unsafe_t && m >= p.thr_hi) hi = lag;
                         }
                     }

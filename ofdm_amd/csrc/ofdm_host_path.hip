@@ -314,6 +314,45 @@ bool long_geometry(const ofdm_ctx *c, int64_t n, int64_t lag_lo, int64_t lag_hi,
     return true;
 }
 
+// Pass 1 of the long search: which slice holds the first threshold crossing of [lag_lo, lag_hi) among its OWN lags.  On a hit
+// *hit >= 0 and *d_clip = the capture's lag of that slice's peak with the window CLIPPED to the slice's own lags, so
+// d_clip - W <= first crossing <= d_clip <= true peak.  Leaves the per-slice outputs in hp->d_scal (s_fd | s_d | s_m).
+struct LongHit { int64_t hit = -1, d_clip = -1, start = 0, flen = 0, own = 0, lags2 = 0, ns = 0; };
+int sc_long_find(ofdm_ctx *c, HostPipe *hp, const float2 *in, int64_t n, const LongGeom &g, LongHit &h) {
+    const int64_t ns = g.n_full + (g.tail_len > 0 ? 1 : 0);
+    h.ns = ns;
+    if (ns > 0x7fffffff) return OFDM_ERR_INVALID;
+    int rc;
+    if ((rc = dev_grow(c, hp, hp->d_scal, (size_t)ns * 16 + 64))) return rc;
+    if ((rc = pin_grow(c, hp, hp->h_scal, (size_t)ns * 4 + 64))) return rc;
+    double *s_fd = static_cast<double *>(hp->d_scal.p);                       // [ns] f64 | [ns] i32 | [ns] f32
+    int32_t *s_d = reinterpret_cast<int32_t *>(s_fd + ns);
+    float *s_m = reinterpret_cast<float *>(s_d + ns);
+    // n_lags = own clips the peak window, so only "d_hat >= 0" and the bracket above are used.  One launch over every lag: a long
+    // capture is mostly noise, where the two-launch search of the batch path would read everything twice.
+    const int first_lags = c->tune.sc_first_lags;
+    c->tune.sc_first_lags = 0;
+    rc = OFDM_OK;
+    if (g.n_full) rc = ofdm_abi_sc_run(c, in + g.lo, g.n_full, g.own, g.own + g.halo, g.own, s_d, s_fd, s_m);
+    if (!rc && g.tail_len > 0)
+        rc = ofdm_abi_sc_run(c, in + g.tail_lo, 1, g.tail_len, g.tail_len, g.hi - g.tail_lo, s_d + g.n_full, s_fd + g.n_full, s_m + g.n_full);
+    c->tune.sc_first_lags = first_lags;
+    if (rc) return rc;
+    int32_t *h_d = static_cast<int32_t *>(hp->h_scal.p);
+    HIP_TRY(c, hipMemcpyAsync(h_d, s_d, 4 * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < ns; i++)
+        if (h_d[i] >= 0) { h.hit = i; break; }
+    if (h.hit < 0) return OFDM_OK;
+    const bool tail = h.hit == g.n_full;
+    h.start = tail ? g.tail_lo : g.lo + h.hit * g.own;
+    h.flen = tail ? g.tail_len : g.own + g.halo;
+    h.own = tail ? g.hi - g.tail_lo : g.own;
+    h.lags2 = std::min(h.own + g.W, g.valid - h.start); // the slice's lags with the whole peak window, as far as the capture has them
+    h.d_clip = h.start + h_d[h.hit];
+    return OFDM_OK;
+}
+
 // The detection whose first threshold crossing lies in [lag_lo, lag_hi): -1, or the capture's lag with CFO and metric.
 int sc_long(ofdm_ctx *c, const float2 *in, int64_t n, int64_t lag_lo, int64_t lag_hi, int64_t slice_lags, int64_t *d_hat, double *f_delta,
             float *metric) {
@@ -325,45 +364,24 @@ int sc_long(ofdm_ctx *c, const float2 *in, int64_t n, int64_t lag_lo, int64_t la
     HostPipe *hp;
     int rc = pipe_get(c, &hp);
     if (rc) return rc;
-    const int64_t ns = g.n_full + (g.tail_len > 0 ? 1 : 0);
-    if (ns > 0x7fffffff) return OFDM_ERR_INVALID;
-    if ((rc = dev_grow(c, hp, hp->d_scal, (size_t)ns * 16 + 64))) return rc;
-    if ((rc = pin_grow(c, hp, hp->h_scal, (size_t)ns * 4 + 64))) return rc;
-    double *s_fd = static_cast<double *>(hp->d_scal.p);                       // [ns] f64 | [ns] i32 | [ns] f32
-    int32_t *s_d = reinterpret_cast<int32_t *>(s_fd + ns);
-    float *s_m = reinterpret_cast<float *>(s_d + ns);
-    // pass 1: which slices hold a crossing among their OWN lags (n_lags = own clips the peak window, so only d_hat >= 0 is used).
-    // One launch over every lag: a long capture is mostly noise, where the two-launch search of the batch path reads everything twice.
-    const int first_lags = c->tune.sc_first_lags;
-    c->tune.sc_first_lags = 0;
-    if (g.n_full) rc = ofdm_abi_sc_run(c, in + g.lo, g.n_full, g.own, g.own + g.halo, g.own, s_d, s_fd, s_m);
-    if (!rc && g.tail_len > 0)
-        rc = ofdm_abi_sc_run(c, in + g.tail_lo, 1, g.tail_len, g.tail_len, g.hi - g.tail_lo, s_d + g.n_full, s_fd + g.n_full, s_m + g.n_full);
-    c->tune.sc_first_lags = first_lags;
-    if (rc) return rc;
-    int32_t *h_d = static_cast<int32_t *>(hp->h_scal.p);
-    HIP_TRY(c, hipMemcpyAsync(h_d, s_d, 4 * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    int64_t hit = -1;
-    for (int64_t i = 0; i < ns; i++)
-        if (h_d[i] >= 0) { hit = i; break; }
-    if (hit < 0) return OFDM_OK;
-    // pass 2: that slice again with its whole peak window (W more lags, as far as the capture has them)
-    const bool tail = hit == g.n_full;
-    const int64_t start = tail ? g.tail_lo : g.lo + hit * g.own;
-    const int64_t flen = tail ? g.tail_len : g.own + g.halo;
-    const int64_t own = tail ? g.hi - g.tail_lo : g.own;
-    const int64_t lags2 = std::min(own + g.W, g.valid - start);
+    LongHit hit;
+    if ((rc = sc_long_find(c, hp, in, n, g, hit))) return rc;
+    if (hit.hit < 0) return OFDM_OK;
+    double *s_fd = static_cast<double *>(hp->d_scal.p);
+    int32_t *s_d = reinterpret_cast<int32_t *>(s_fd + hit.ns);
+    float *s_m = reinterpret_cast<float *>(s_d + hit.ns);
+    // pass 2: that slice again with its whole peak window (a slice that ends with the capture's last lag had it in pass 1 already)
     struct { double fd; int32_t d; float m; } h;
-    h.d = h_d[hit];
-    const int64_t at = lags2 > own ? 0 : hit; // a slice that ends with the capture's last lag had its whole window in pass 1 already
-    if (lags2 > own && (rc = ofdm_abi_sc_run(c, in + start, 1, flen, flen, lags2, s_d, s_fd, s_m))) return rc;
+    h.d = (int32_t)(hit.d_clip - hit.start);
+    const bool again = hit.lags2 > hit.own;
+    const int64_t at = again ? 0 : hit.hit;
+    if (again && (rc = ofdm_abi_sc_run(c, in + hit.start, 1, hit.flen, hit.flen, hit.lags2, s_d, s_fd, s_m))) return rc;
     HIP_TRY(c, hipMemcpyAsync(&h.fd, s_fd + at, 8, hipMemcpyDeviceToHost, c->stream));
-    if (lags2 > own) HIP_TRY(c, hipMemcpyAsync(&h.d, s_d, 4, hipMemcpyDeviceToHost, c->stream));
+    if (again) HIP_TRY(c, hipMemcpyAsync(&h.d, s_d, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&h.m, s_m + at, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (h.d < 0) return OFDM_OK; // cannot happen (pass 1 saw a crossing among these lags); keep "no detection" rather than a wrong lag
-    *d_hat = start + h.d;
+    *d_hat = hit.start + h.d;
     if (f_delta) *f_delta = h.fd;
     if (metric) *metric = h.m;
     return OFDM_OK;
@@ -384,16 +402,23 @@ int decode_long_dev(ofdm_ctx *c, const float2 *in, int64_t n, int64_t lag_lo, in
     const bool whole = lag_lo == 0 && (lag_hi <= 0 || lag_hi >= n - (int64_t)(c->prm.sync_window_reps + 1) * c->S() + 1);
     const bool one_frame = whole && d_known < 0 && (!long_geometry(c, n, 0, 0, 0, g) || g.n_full == 0);
     if (c->prm.sync_mode == OFDM_SYNC_SCHMIDL_COX && !one_frame) { // (a capture no longer than one slice is one frame of the batch path)
-        int64_t d = d_known;
-        if (d < 0 && (rc = sc_long(c, in, n, lag_lo, lag_hi, 0, &d, nullptr, nullptr))) return rc;
-        if (d < 0) return OFDM_OK;
-        // Decode from a sub-capture that starts at or before both the first crossing (d1 >= d - W) and the trimmed frame start
-        // (d - L - backoff): its own search finds the same crossing, window, peak and offset as the whole capture's, and every
-        // length the chain derives from "samples after the trimmed start" is unchanged.
+        // Decode from a SUB-CAPTURE that starts at or before both the first crossing d1 and the trimmed frame start
+        // (peak - L - backoff): its own search finds the same crossing, window, peak and offset as the whole capture's, and every
+        // length the chain derives from "samples after the trimmed start" is unchanged.  A known peak d gives d1 >= d - W; pass 1 of
+        // the slice search gives a clipped peak dc with dc - W <= d1 <= dc <= peak -- enough to place the sub-capture without
+        // pass 2 (the chain's own search redoes that work on a few hundred samples anyway).
         const int L = c->S(), W = c->prm.sync_window_reps * L;
-        const int64_t back = std::max<int64_t>(W, (int64_t)L + c->prm.sync_backoff);
-        start = std::max<int64_t>(d - back, 0) & ~(int64_t)1; // even: the sub-capture stays 16-byte aligned for the LDS-DMA kernels
-        sub_lags = d - start + W + 2;                          // the search clips it to the capture's own last lag
+        int64_t d_lo = d_known, d_hi = d_known; // bracket of the first crossing: d1 in [d_lo - W, d_hi]
+        if (d_known < 0) {
+            if (!long_geometry(c, n, lag_lo, lag_hi, 0, g)) return OFDM_OK;
+            LongHit hit;
+            if ((rc = sc_long_find(c, hp, in, n, g, hit))) return rc;
+            if (hit.hit < 0) return OFDM_OK;
+            d_lo = d_hi = hit.d_clip;
+        }
+        const int64_t back = (int64_t)W + L + c->prm.sync_backoff;
+        start = std::max<int64_t>(d_lo - back, 0) & ~(int64_t)1; // even: the sub-capture stays 16-byte aligned for the LDS-DMA kernels
+        sub_lags = d_hi - start + W + 2;                           // covers d1 + W; the search clips it to the capture's own last lag
     } else if (c->prm.sync_mode != OFDM_SYNC_SCHMIDL_COX && !whole) {
         return OFDM_ERR_UNSUPPORTED; // the reference's detector is an argmax over the whole capture (src/receiver.rs:20-25)
     }

@@ -6,7 +6,7 @@
 #      combined with a trace: MI355X_MICROARCH.md, HBM + rocprofv3 sections)
 # rocprofv3 writes its (large) traces under /tmp; only the summaries are copied back.
 set -o pipefail
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT="$PWD/gpurun_out/prof"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH_ARGS=${BENCH_ARGS:-}
@@ -18,6 +18,19 @@ f=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1)
 test -n "$f" || exit 3
 ( head -1 "$f"; grep "ofdm::" "$f" ) > "$OUT/${ROUND}_bench_kernel_stats_ofdm_only.csv"
 echo "kernel trace done"
+fi
+# 2b. clean per-configuration passes: ONE timed configuration per process (tools/prof_clean.py), so that a kernel's average is the
+#     average of the measured launches only -- the every-lag k_sc_cf<256,2,4,0> (which the bench run also launches over near-empty
+#     redo lists), the config-3 / config-4 chains on the stated and on the late-packet placement, config 5
+if [ -z "$SKIP_CLEAN" ]; then
+for w in sc_every_lag cfg3_chain cfg3_late cfg4_chain cfg4_late cfg5; do
+  rm -rf /tmp/prof_clean_$w
+  ( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_clean_$w -- python3 "$OLDPWD/tools/prof_clean.py" $w > "$OUT/${ROUND}_clean_$w.json" 2> "$OUT/${ROUND}_clean_$w.err" ) || exit 6
+  f=$(find /tmp/prof_clean_$w -name "*kernel_stats.csv" | head -1)
+  test -n "$f" || exit 7
+  ( head -1 "$f"; grep "ofdm::" "$f" ) > "$OUT/${ROUND}_clean_${w}_kernel_stats.csv"
+  echo "clean $w done"
+done
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$c -- python3 "$OLDPWD/tools/pmc_probe.py" > "$OUT/${ROUND}_pmc_$c.log" 2>&1 ) || exit 4
