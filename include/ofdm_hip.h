@@ -132,7 +132,10 @@ int ofdm_last_dispatch(const ofdm_ctx *ctx, char *buf, size_t n);
  * "tx_waves", "txframe_keep_steps" (1: frames that fit one step of k_txframe_mid are built once; 0: always twice), "sc_wg_per_cu", "sc_first_lags" (N = 64 searches: lags of the first of two launches, 0 = one launch), "sc128_one_wave" (1: one wavefront per frame in the 128-chunk k_sc_cf), "demod64_wg_per_cu", "demod64_burst" (16 / 8 / 4 / 1), "demod64_narrow_stores",
  * "scb_two_segments", "scb_big_tiles"; "debug_demod64", "debug_sc", "debug_tx" select ablation exits / section timers
  * that exist only in the profile build of the library (libofdm_hip_profile.so, -DOFDM_PROFILE_BUILD=1): the product build
- * answers OFDM_ERR_UNSUPPORTED.  Unknown key: OFDM_ERR_INVALID.  ofdm_get_tuning also answers "profile_build". Host calls. */
+ * answers OFDM_ERR_UNSUPPORTED.  Unknown key: OFDM_ERR_INVALID.  ofdm_get_tuning also answers "profile_build" and two counters of
+ * the context's LAST N = 64 Schmidl-Cox search (it synchronises the stream; -1 = that search kept no such list): "stat_sc_slow_frames"
+ * (frames the f32 filter handed to the all-f64 kernel) and "stat_sc_redo_frames" (frames the first launch of the two-launch search
+ * left to the whole search).  Host calls. */
 int ofdm_set_tuning(ofdm_ctx *ctx, const char *key, int64_t value);
 int ofdm_get_tuning(const ofdm_ctx *ctx, const char *key, int64_t *value);
 

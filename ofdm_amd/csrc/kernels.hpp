@@ -50,6 +50,14 @@ struct Trace {
 };
 inline void trace_add(Trace *t, const char *name) { if (t) t->add(name); }
 
+// Device-side counters of the last Schmidl-Cox search on a context (ofdm_get_tuning "stat_sc_slow_frames" / "stat_sc_redo_frames"):
+// how many frames the f32 filter handed to the all-f64 kernel, and how many the first launch of the two-launch search left to
+// the whole search.  Pointers into the search's workspace; nullptr when the last search kept no such list.
+struct ScStats {
+    const int32_t *slow_count = nullptr;
+    const int32_t *redo_count = nullptr;
+};
+
 struct SymParams {
     const Tuning *tune = nullptr; // nullptr = defaults
     Trace *trace = nullptr;
@@ -156,6 +164,7 @@ struct ScParams {
     float *metric = nullptr;
     const int32_t *slow_list = nullptr;  // k_sc_tile list mode: frames to (re)do, count in *slow_count
     const int32_t *slow_count = nullptr;
+    ScStats *stats = nullptr;            // optional: where the search leaves the addresses of its list counters
 };
 size_t sc_lds_bytes(const ScParams &p);
 hipError_t run_sc(const ScParams &p, hipStream_t st);

@@ -231,7 +231,7 @@ int sc_tile_lags() { return SC_CH; }
 //     all-f64 kernel k_sc_tile.  Outputs equal the f64 oracle's.
 constexpr float SC_EPS = 1e-3f;         // relative guard band of the f32 filter around the threshold / the maximum
 constexpr float SC_UNSAFE_RATIO = 20.f; // prefix energy / window energy above which a lag is never trusted
-constexpr float SC_PREFIX_ERR = 1.6e-5f; // bound on |f32 window sum - exact| / prefix magnitude (the scans and slides stay below 4e-6; x 4 for margin)
+constexpr float SC_PREFIX_ERR = 1.6e-5f; // bound on |f32 window sum - exact| / prefix magnitude when PROVING a lag below the threshold (the scans and slides stay below 4e-6; x 4 for margin)
 constexpr int SC_MAXCAND = 4;
 
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_d(double x) {
@@ -478,7 +478,27 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
     if (RX && tid < 64) twl[tid] = p.rx.tw[tid];
     cf itrn = make_float2(0.f, 0.f);  // 1 / training[bitrev6(lane)]: the bin this lane holds after the lane FFT
     if (RX) itrn = p.rx.inv_training[bitrev6(lane)];
-    auto to_redo = [&](long long fr) { p.redo_list[atomicAdd(p.redo_count, 1)] = (int32_t)fr; };
+    // Frames the first lags do not determine go to the device-side redo list in BATCHES: with one atomicAdd per frame on the one
+    // counter, a batch in which every frame defers (late packets, empty slots) spent 1.5 ms per 131 072 frames waiting for that
+    // address; a workgroup now collects up to 16 of its frames in LDS and reserves their list slots with one atomic.  Writers are
+    // thread 0 (no flagged chunk) or lane 0 of the fine wavefront, in different phases of a frame, always barriers apart.
+    constexpr int RB = 16;
+    int *rbuf = reinterpret_cast<int *>(flg + VW);          // !RX only: [0] pending, [1 .. RB] frames
+    auto redo_flush = [&]() {
+        const int m = rbuf[0];
+        if (m > 0) {
+            const int base = atomicAdd(p.redo_count, m);
+            for (int i = 0; i < m; ++i) p.redo_list[base + i] = rbuf[1 + i];
+            rbuf[0] = 0;
+        }
+    };
+    auto to_redo = [&](long long fr) {
+        const int m = rbuf[0];
+        rbuf[1 + m] = (int32_t)fr;
+        rbuf[0] = m + 1;
+        if (m + 1 == RB) redo_flush();
+    };
+    if (!RX && tid == 0) rbuf[0] = 0;
     const bool listed = !RX && p.frame_list != nullptr;
     const long long n_items = listed ? (long long)*p.frame_count : p.n_frames;
     auto frame_of = [&](long long item) -> long long { return listed ? (long long)p.frame_list[item] : item; };
@@ -606,7 +626,12 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                     const int v0 = cb >> 6, v2 = (cb + cL) >> 6;
                     const bool xP = ((cb + cW) >> 6) != v0, xR = ((cb + cW + cL) >> 6) != v2;
                     const float t0r = wtot[v0 * 4 + 0], t0i = wtot[v0 * 4 + 1], t0e = wtot[v0 * 4 + 2], t2e = wtot[v2 * 4 + 2];
-                    const float etop = e3 + t0e + t2e; // magnitude of the terms behind E and R (cancellation bound)
+                    // magnitude of the prefixes behind each sum (what its f32 cancellation error scales with): a wave-local prefix holds
+                    // the energy from its virtual wavefront's first chunk up to the entry, plus that wavefront's total when the difference
+                    // leaves it.  (Round 3 charged e3 + t0e + t2e against every sum: in front of a LATE packet, where the window is noise
+                    // and the totals are packet energy, every lag then looked untrusted and the whole frame went to the all-f64 kernel.)
+                    const float magE = fmaxf(e0, e1) + (xP ? t0e : 0.f), magR = fmaxf(e2, e3) + (xR ? t2e : 0.f);
+                    const float magP = fmaxf(magE, magR) + (v2 != v0 ? t0e : 0.f); // |q[n]| <= (e[n] + e[n+L]) / 2
                     cf sa[5], sb[5], sc[5], sd[5];
 #pragma unroll
                     for (int k = 0; k < 5; ++k) { // low sample x of the step to round k's lag (forward k = 0 sits on the boundary: no step)
@@ -615,7 +640,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                     }
                     float Pr = (q1.x - q0.x) + (xP ? t0r : 0.f), Pi = (q1.y - q0.y) + (xP ? t0i : 0.f);
                     float E = (e1 - e0) + (xP ? t0e : 0.f), R = (e3 - e2) + (xR ? t2e : 0.f);
-                    float emin = 3.0e38f, mmax = -1.f;
+                    float emE = 3.0e38f, emR = 3.0e38f, mmax = -1.f;
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {
                         const float wk = (hh || k > 0) ? sgn : 0.f;
@@ -628,21 +653,23 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                         const float den = E * R;
                         const bool ok = den > 0.f && lag < n;
                         mp[k] = ok ? (Pr * Pr + Pi * Pi) * __builtin_amdgcn_rcpf(den) : -1.f;
-                        emin = fminf(emin, ok ? fminf(E, R) : 3.0e38f);
+                        emE = fminf(emE, ok ? E : 3.0e38f);
+                        emR = fminf(emR, ok ? R : 3.0e38f);
                         mmax = fmaxf(mmax, mp[k]);
                     }
-                    unsafe_t = etop > SC_UNSAFE_RATIO * emin; // emin stays huge when no lag has energy
-                    // An untrusted lag is not yet a possible crossing.  In front of a late packet the window holds noise while the
-                    // prefixes behind it already carry packet energy (ratios of 10^3 .. 10^4): the sums are too coarse to place the
-                    // metric within SC_EPS, but not too coarse to prove it far below the threshold.  Every sum is off by at most
-                    // SC_PREFIX_ERR x the prefix magnitude, i.e. by er = SC_PREFIX_ERR etop / emin relative to the smallest window
-                    // energy, so M <= (sqrt(M_f32) + er)^2 / (1 - er)^2; lags that stay below the threshold under that bound cannot
-                    // cross (without this every frame whose packet starts more than W samples into its slot went to the slow list).
+                    // trusted to within SC_EPS: every sum's error (<= 4e-6 x its prefix magnitude) is below 1e-4 of the sum itself --
+                    // E and R against themselves, |P| against sqrt(E R) (M near the threshold means |P| ~ 0.7 sqrt(E R))
+                    const float gmin = __builtin_amdgcn_sqrtf(emE) * __builtin_amdgcn_sqrtf(emR); // the minima stay huge when no lag has energy
+                    unsafe_t = magE > SC_UNSAFE_RATIO * emE || magR > SC_UNSAFE_RATIO * emR || magP > SC_UNSAFE_RATIO * gmin;
+                    // An untrusted lag is not yet a possible crossing: sums too coarse to place M within SC_EPS can still prove it far
+                    // below the threshold.  With every sum off by at most SC_PREFIX_ERR x its prefix magnitude,
+                    //     sqrt(M) <= (sqrt(M_f32) + 1.5 dP / sqrt(E R)) / sqrt((1 - dE / E)(1 - dR / R))
+                    // over the lane's lags (worst E, R and M of the five); lags that stay below the threshold under it cannot cross.
                     bool maybe = unsafe_t;
                     if (unsafe_t && mmax >= 0.f) {
-                        const float er = SC_PREFIX_ERR * etop * __builtin_amdgcn_rcpf(emin);
-                        const float up = __builtin_amdgcn_sqrtf(mmax) + 1.5f * er, dn = 1.f - er; // |P| is off by up to sqrt(2) such errors
-                        maybe = !(er < 0.25f && up * up < p.thr_lo * dn * dn);
+                        const float erE = SC_PREFIX_ERR * magE * __builtin_amdgcn_rcpf(emE), erR = SC_PREFIX_ERR * magR * __builtin_amdgcn_rcpf(emR);
+                        const float up = __builtin_amdgcn_sqrtf(mmax) + 1.5f * SC_PREFIX_ERR * magP * __builtin_amdgcn_rcpf(gmin);
+                        maybe = !(erE < 0.25f && erR < 0.25f && up * up < p.thr_lo * (1.f - erE) * (1.f - erR));
                     }
                     if (maybe || mmax >= p.thr_lo) {
 #pragma unroll
@@ -898,12 +925,16 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
             p.rx.metric[f] = (float)dt[dbg - 20 < 7 ? dbg - 20 : 6];
         }
     }
+    if (!RX && p.defer) { // the frames still waiting in this workgroup's LDS batch
+        lds_barrier();
+        if (tid == 0) redo_flush();
+    }
 }
 static size_t sc_cf_lds_bytes(int L, int nch, long long frame_len, bool rx) { // raw samples + chunk prefixes, energies, flags
     long long ns = ((frame_len + 1) / 2 * 2 + 9) / 10 * 10;
     if (ns > (long long)nch * 10) ns = (long long)nch * 10;
     return (size_t)(ns + L) * sizeof(float2) + (size_t)(nch + 2) * (sizeof(float2) + sizeof(float)) + (size_t)nch * sizeof(float) +
-           16 * sizeof(float) + 64 + 16 + (rx ? 48 + 64 * sizeof(float2) : 0);
+           16 * sizeof(float) + 64 + 16 + (rx ? 48 + 64 * sizeof(float2) : 80 /* the redo batch: count + 16 frames */);
 }
 
 // chunks per frame (128 / 256, 10 samples each): the smallest tile that covers the searched lags plus the window
@@ -951,6 +982,7 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     int32_t *redo_list = redo_count + 4;
     if (slow_list_out) *slow_list_out = slow_list;
     if (slow_count_out) *slow_count_out = slow_count;
+    if (p.stats) { p.stats->slow_count = slow_count; p.stats->redo_count = nullptr; }
     hipError_t e = hipMemsetAsync(slow_count, 0, 16, st);
     if (e != hipSuccess) return e;
     ScFastParams q;
@@ -1006,6 +1038,7 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         bool two_phase = first > 0 && p.n_lags >= 2LL * first && (long long)128 * 10 - p.W - p.L - 12 >= first && first > p.W + 1;
         if (two_phase) {
             if ((e = hipMemsetAsync(redo_count, 0, 16, st)) != hipSuccess) return e;
+            if (p.stats) p.stats->redo_count = redo_count;
             ScFastParams q1 = q;
             q1.n_lags = first; q1.defer = 1;
             long long stage1 = (first + p.W + p.L + 10 + 1) & ~1LL;

@@ -397,6 +397,17 @@ int ofdm_get_tuning(const ofdm_ctx *c, const char *key, int64_t *value) {
     if (!c || !key || !value) return OFDM_ERR_INVALID;
     if (std::strcmp(key, "grid_cap") == 0) { *value = c->tune.grid_cap; return OFDM_OK; }
     if (std::strcmp(key, "profile_build") == 0) { *value = kProfile ? 1 : 0; return OFDM_OK; }
+    if (std::strcmp(key, "stat_sc_slow_frames") == 0 || std::strcmp(key, "stat_sc_redo_frames") == 0) {
+        // counters of the LAST Schmidl-Cox search of this context (synchronises its stream); -1 when that search kept no such list
+        const int32_t *src = key[8] == 's' ? c->sc_stats.slow_count : c->sc_stats.redo_count;
+        *value = -1;
+        if (!src) return OFDM_OK;
+        DeviceGuard dev_guard(c->device);
+        int32_t v = 0;
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, src, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return OFDM_ERR_HIP;
+        *value = v;
+        return OFDM_OK;
+    }
     for (const TuneKey &k : kTuneKeys)
         if (std::strcmp(key, k.name) == 0) { *value = c->tune.*(k.field); return OFDM_OK; }
     return OFDM_ERR_INVALID;
@@ -581,6 +592,8 @@ static bool sc_make_params(ofdm_ctx *c, const float2 *in, int64_t n_frames, int6
     p.d_hat = d_hat; p.f_delta = f_delta; p.metric = metric;
     p.tiles_per_frame = 1; p.mode = 0;
     p.tune = &c->tune; p.trace = &c->trace;
+    c->sc_stats = ScStats();
+    p.stats = &c->sc_stats;
     return true;
 }
 

@@ -28,6 +28,7 @@ struct ofdm_ctx {
     float header_max = 0.f;
     ofdm::Tuning tune;                  // ofdm_set_tuning: per-context A/B switches and grid shapes (no environment variable is read)
     ofdm::Trace trace;                  // ofdm_last_dispatch: the kernels the last entry point launched
+    ofdm::ScStats sc_stats;             // list counters of the last Schmidl-Cox search (ofdm_get_tuning "stat_sc_*")
     // workspaces (grown on demand, never inside a captured region)
     Workspace ws[8];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
