@@ -43,9 +43,32 @@ template <int R> struct Mid {
     // registers and spills 10-20 of them under the 128-VGPR limit of 4 waves (measured: N = 1024 RX 0.30 -> 0.45 of the
     // roofline at 3 waves, TX 0.49 -> 0.44 -- TX has no spills at 4)
     static constexpr int OCC_RX = R >= 16 ? 3 : 4, OCC_TX = 4;
-    // row slot of output row c in the transpose buffer: the Q lanes of a column write ADJACENT rows (16 banks apart)
-    __device__ static int slot_of_row(int c) { return R >= 8 ? (c & 7) * Q + (c >> 3) : c; }
-    __device__ static int row_of_slot(int rho) { return R >= 8 ? rho / Q + 8 * (rho % Q) : rho; }
+    // Row slot of output row c = e + 8 u (stage-A output e of the column's lane u) in the transpose buffer.  A stage-A store has the
+    // lanes of a half wavefront write one row slot each per lane group u, 32 / Q consecutive columns wide; rows are 72 samples = 144
+    // banks apart, i.e. 16 banks per slot (mod 64), so the slots of the Q groups must differ by 64 / Q banks: Q = 4: adjacent slots
+    // (u), Q = 2: slots 2 apart (round 3 used adjacent slots for Q = 2 as well: the second half of group 0's 16 columns shared its
+    // banks with the first half of group 1's -- a 2-way conflict on every stage-A store of N = 1024).
+    __device__ static int slot_of_row(int c) {
+        if (R < 8) return c;
+        const int e = c & 7, u = c >> 3;
+        return Q == 2 ? 2 * u + (e & 1) + 4 * (e >> 1) : e * Q + u;
+    }
+    __device__ static constexpr int slot_of_eu(int e, int u) { return Q == 2 ? 2 * u + (e & 1) + 4 * (e >> 1) : e * Q + u; }
+    __device__ static int row_of_slot(int rho) {
+        if (R < 8) return rho;
+        return Q == 2 ? ((rho & 1) + 2 * (rho >> 2)) + 8 * ((rho >> 1) & 1) : rho / Q + 8 * (rho % Q);
+    }
+    // Where sample n of a symbol sits in the SECOND transpose of the TX kernels (sample order, so that the stores are 16 bytes per
+    // lane): row n / 64, column n % 64 -- for R >= 16 with the column XOR-ed by 2 (row mod 4) and by 4 (column / 32).  A lane writes
+    // n = cB + R (t + 8 q); unswizzled, the bank of that store depends on t / 2 and on two bits of cB only, and they ADD: 8 lanes of a
+    // half wavefront per bank pair at R = 32 (PMC round 3: 53 % of k_tx_mid<32>'s LDS cycles were conflicts), 4 at R = 16.  The XORs
+    // put the row into bits 1-2 and the upper half of the row into bit 2: conflict-free at R = 16, 2-way at R = 32 (all of a half
+    // wavefront's columns are even there: 16 bank pairs for 32 lanes is the floor).  Both XORs are even, so sample pairs stay
+    // adjacent and 16-byte aligned for the float4 reads of the store loop.
+    __device__ static int t2_index(int n) {
+        const int row = n >> 6, col = n & 63;
+        return row * TS + (R >= 16 ? col ^ (2 * (row & 3)) ^ (4 * (col >> 5)) : col);
+    }
 };
 
 template <int LPS> __device__ __forceinline__ void symbol_sync() {
@@ -248,7 +271,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
         stage_a<R, false>(v, tA, u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int slot = R >= 8 ? e * Q + u : e % R;
+            const int slot = R >= 8 ? M::slot_of_eu(e, u) : e % R; // = slot_of_row(e + 8 u), with e a compile-time constant
             const int col = R >= 8 ? colA : colA + LPS * (e / R);
             T[(g * R + slot) * TS + col] = (R < 8 && e % R == 0) ? v[e] : cmul(v[e], z[e]);
         }
@@ -461,7 +484,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
         stage_a<R, true>(v, tA, u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int slot = R >= 8 ? e * Q + u : e % R;
+            const int slot = R >= 8 ? M::slot_of_eu(e, u) : e % R; // = slot_of_row(e + 8 u), with e a compile-time constant
             const int col = R >= 8 ? colA : colA + LPS * (e / R);
             Tsym[slot * TS + col] = (R < 8 && e % R == 0) ? v[e] : cmul(v[e], z[e]);
         }
@@ -478,7 +501,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = cB + R * (t + 8 * q);
-            Tsym[(n >> 6) * TS + (n & 63)] = make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N));
+            Tsym[M::t2_index(n)] = make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N));
         }
         symbol_sync<LPS>();
         if (sg < p.n_sym) { // prefix_block: out = [x[N - CP .. N), x[0 .. N)]
@@ -486,7 +509,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = l + LPS * j, n = 2 * i;                        // sample pair (n, n + 1)
-                const float4 y = *reinterpret_cast<const float4 *>(Tsym + (n >> 6) * TS + (n & 63));
+                const float4 y = *reinterpret_cast<const float4 *>(Tsym + M::t2_index(n));
                 dst4[(CP >> 1) + i] = y;
                 if (j == 3) dst4[i - ((N - CP) >> 1)] = y;                   // n >= N - CP: the cyclic prefix
             }
@@ -610,7 +633,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
         stage_a<R, true>(v, tA, u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int slot = R >= 8 ? e * Q + u : e % R;
+            const int slot = R >= 8 ? M::slot_of_eu(e, u) : e % R; // = slot_of_row(e + 8 u), with e a compile-time constant
             const int col = R >= 8 ? colA : colA + LPS * (e / R);
             Tsym[slot * TS + col] = (R < 8 && e % R == 0) ? v[e] : cmul(v[e], z[e]);
         }
@@ -627,7 +650,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = cB + R * (t + 8 * q);
-            Tsym[(n >> 6) * TS + (n & 63)] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
+            Tsym[M::t2_index(n)] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
         }
         symbol_sync<LPS>();
         if (valid) {
@@ -635,7 +658,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = l + LPS * j, n = 2 * i;
-                const float4 y = *reinterpret_cast<const float4 *>(Tsym + (n >> 6) * TS + (n & 63));
+                const float4 y = *reinterpret_cast<const float4 *>(Tsym + M::t2_index(n));
                 dst4[(CP >> 1) + i] = y;
                 if (j == 3) dst4[i - ((N - CP) >> 1)] = y;
             }
