@@ -129,7 +129,7 @@ int ofdm_last_dispatch(const ofdm_ctx *ctx, char *buf, size_t n);
  * Keys (value >= 0): "one_pass_rx" 0/1 (overrides ofdm_params.rx_path), "no_sc_stream", "no_sc_big", "no_rx1024_finish", "no_fast64", "no_demod4096",
  * "no_mid_kernels", "no_rxframe1024", "no_txframe64" (1 = take the generic kernel instead of that family), "grid_cap"
  * (> 0: caps every persistent grid -- the tests use it to run many pipeline steps per workgroup on small batches),
- * "tx_waves", "txframe_keep_steps" (1: frames that fit one step of k_txframe_mid are built once; 0: always twice), "sc_wg_per_cu", "sc_first_lags" (N = 64 searches: lags of the first of two launches, 0 = one launch), "sc128_one_wave" (1: one wavefront per frame in the 128-chunk k_sc_cf), "demod64_wg_per_cu", "demod64_burst" (16 / 8 / 4 / 1), "demod64_narrow_stores",
+ * "tx_waves", "txframe_keep_steps" (1: frames that fit one step of k_txframe_mid are built once; 0: always twice), "txframe_rewrite" (1: longer frames are built once, stored unnormalised and rescaled in a second sweep -- measured slower, A/B only), "sc_wg_per_cu", "sc_first_lags" (N = 64 searches: lags of the first of two launches, 0 = one launch), "sc128_one_wave" (1: one wavefront per frame in the 128-chunk k_sc_cf), "demod64_wg_per_cu", "demod64_burst" (16 / 8 / 4 / 1), "demod64_narrow_stores",
  * "scb_two_segments", "scb_big_tiles"; "debug_demod64", "debug_sc", "debug_tx" select ablation exits / section timers
  * that exist only in the profile build of the library (libofdm_hip_profile.so, -DOFDM_PROFILE_BUILD=1): the product build
  * answers OFDM_ERR_UNSUPPORTED.  Unknown key: OFDM_ERR_INVALID.  ofdm_get_tuning also answers "profile_build" and two counters of

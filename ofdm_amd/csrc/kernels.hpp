@@ -23,6 +23,8 @@ struct Tuning {
     long long grid_cap = 0;        // > 0: caps every persistent grid (test hook: many steps per workgroup on a small batch)
     int tx_waves = 16;             // k_txframe64: wavefronts per CU
     int txframe_keep_steps = 1;    // k_txframe_mid: 1 = frames whose data symbols fit ONE workgroup step (<= 32 / R symbols) are built once, their points kept in registers until the maximum is known; 0 = always twice
+    int txframe_rewrite = 0;       // k_txframe_mid, frames of more than one step: 1 = build every symbol ONCE -- unnormalised samples out, then a rescale sweep over what
+                                   // was just written (L2 / memory-side cache) -- instead of building every symbol twice
     int sc_wg_per_cu = 7;          // k_sc_cf: persistent workgroups per CU
     int sc128_one_wave = 1;        // k_sc_cf over <= 960 lags: one wavefront per frame (two chunks per lane, 15 frames per CU, no wavefront idling through the fine pass) instead of two (0: A/B); measured 1.46 -> 1.31 ms per 262 144 config-3 frames over all lags, 1.43 -> 1.25 bounded
     int sc_first_lags = 384;       // k_sc_cf, searches of >= twice as many lags: the lags the first launch looks at (0 = one launch over every lag).

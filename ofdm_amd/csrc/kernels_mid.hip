@@ -19,6 +19,7 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 extern "C" __device__ float __ocml_atan2pi_f32(float, float); // atan2(y, x) / pi (ROCm device library)
 
@@ -644,13 +645,16 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
         symbol_sync<LPS>(); // T and the byte window are free again
     };
 
-    // the samples of symbol (f0 + fl, k), divided by the frame's maximum, through T into sample order and out (prefix_block: out = [x[N - CP .. N), x[0 .. N)])
-    auto emit = [&](bool valid, long long f0, int fl, int k, const cf *v) {
-        const float mx = fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
+    // the samples of symbol (f0 + fl, k), divided by the frame's maximum, through T into sample order and out (prefix_block: out = [x[N - CP .. N), x[0 .. N)]).
+    // RAW (the build-once scheme): the symbol's N samples go out UNNORMALISED (x 1 / N only) and without the prefix; rescale() finishes them.
+    auto emit = [&](bool valid, long long f0, int fl, int k, const cf *v, auto raw_tag) {
+        constexpr bool RAW = decltype(raw_tag)::value;
+        const float mx = RAW ? 1.f : fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = cB + R * (t + 8 * q);
-            Tsym[M::t2_index(n)] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
+            Tsym[M::t2_index(n)] = RAW ? make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N))
+                                       : make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
         }
         symbol_sync<LPS>();
         if (valid) {
@@ -660,10 +664,28 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
                 const int i = l + LPS * j, n = 2 * i;
                 const float4 y = *reinterpret_cast<const float4 *>(Tsym + M::t2_index(n));
                 dst4[(CP >> 1) + i] = y;
-                if (j == 3) dst4[i - ((N - CP) >> 1)] = y;
+                if (!RAW && j == 3) dst4[i - ((N - CP) >> 1)] = y;
             }
         }
         symbol_sync<LPS>();
+    };
+    // Build-once scheme, second half: every lane takes back exactly the four sample pairs IT stored for symbol (f0 + fl, k) -- they
+    // are minutes old in L2 / the memory-side cache --, divides them by the frame's maximum (the same two roundings as the
+    // two-pass kernel: x / N, then / max) and stores them again, now with the cyclic prefix.
+    auto rescale = [&](bool valid, long long f0, int fl, int k) {
+        if (!valid) return;
+        const float mx = fmaxf(p.header_max, __uint_as_float(fmax[fl]));
+        float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride + (long long)(10 + k) * S);
+        float4 y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = dst4[(CP >> 1) + l + LPS * j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = l + LPS * j;
+            const float4 o = make_float4(y[j].x / mx, y[j].y / mx, y[j].z / mx, y[j].w / mx);
+            dst4[(CP >> 1) + i] = o;
+            if (j == 3) dst4[i - ((N - CP) >> 1)] = o;
+        }
     };
     auto note_max = [&](bool valid, int fl, const cf *v) {
         float mine = 0.f;
@@ -709,8 +731,26 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
                 if (step < steps) {
                     const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
                     const bool valid = sigma < slots && f0 + fl < p.n_frames;
-                    emit(valid, f0, fl, k, vv[step]);
+                    emit(valid, f0, fl, k, vv[step], std::false_type{});
                 }
+            }
+            __syncthreads(); // fmax is reset by the next round
+            continue;
+        }
+        if (KEEP < 0) { // build once: unnormalised samples out, the frame's maximum, then the rescale sweep over what was just written
+            for (int step = 0; step < steps; ++step) {
+                const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
+                const bool valid = sigma < slots && f0 + fl < p.n_frames;
+                cf v[8];
+                build(valid, f0 + fl, k, v);
+                note_max(valid, fl, v);
+                emit(valid, f0, fl, k, v, std::true_type{});
+            }
+            __syncthreads(); // every maximum of the round is final (and this thread's stores are acknowledged: s_waitcnt vmcnt(0))
+            emit_headers(f0);
+            for (int step = 0; step < steps; ++step) {
+                const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
+                rescale(sigma < slots && f0 + fl < p.n_frames, f0, fl, k);
             }
             __syncthreads(); // fmax is reset by the next round
             continue;
@@ -724,7 +764,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
                 cf v[8];
                 build(valid, f0 + fl, k, v);
                 if (pass == 0) { note_max(valid, fl, v); continue; }
-                emit(valid, f0, fl, k, v);
+                emit(valid, f0, fl, k, v, std::false_type{});
             }
             if (pass == 0) {
                 __syncthreads();
@@ -739,7 +779,7 @@ template <int R, int KEEP> static void launch_txframe_mid_k(const MidTxFramePara
     if (guard) hipLaunchKernelGGL((k_txframe_mid<R, true, KEEP>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_txframe_mid<R, false, KEEP>), grid, dim3(256), 0, st, p);
 }
-template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, hipStream_t st, int num_cu, long long cap, int keep_max) {
+template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, hipStream_t st, int num_cu, long long cap, int keep_max, bool rewrite) {
     constexpr int G = Mid<R>::G;
     // a frame whose symbols fit keep_max (<= 4) steps of the workgroup is built ONCE, its points kept in registers until the frame's
     // maximum is known; otherwise frames per round: the count (<= 8, <= 32 slots' worth) that wastes the fewest symbol slots of
@@ -759,6 +799,7 @@ template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, h
     const long long rounds = (p.n_frames + p.fpw - 1) / p.fpw;
     const dim3 grid((unsigned)mid_grid(rounds, num_cu, 3, cap)); // built for 3 waves per SIMD: the twice-inlined symbol builder spills at 4
     if (keep) launch_txframe_mid_k<R, 1>(p, guard, grid, st);
+    else if (rewrite) launch_txframe_mid_k<R, -1>(p, guard, grid, st);
     else launch_txframe_mid_k<R, 0>(p, guard, grid, st);
     return hipGetLastError();
 }
@@ -836,14 +877,15 @@ hipError_t run_txframe_mid(int n_fft, const SymParams &sp, const float2 *header,
     const long long cap = tu.grid_cap;
     const int keep_max = tu.txframe_keep_steps;   // 0 = always build twice (A/B)
     const int G = 32 / R, steps1 = (p.D + G - 1) / G;
-    trace_add(sp.trace, (steps1 <= keep_max && steps1 <= 1) ? "k_txframe_mid<once>" : "k_txframe_mid");
+    const bool rewrite = tu.txframe_rewrite != 0 && !(steps1 <= keep_max && steps1 <= 1);
+    trace_add(sp.trace, (steps1 <= keep_max && steps1 <= 1) ? "k_txframe_mid<once>" : rewrite ? "k_txframe_mid<rewrite>" : "k_txframe_mid");
     switch (R) {
-    case 1: return launch_txframe_mid<1>(p, sp.guard != 0, st, num_cu, cap, keep_max);
-    case 2: return launch_txframe_mid<2>(p, sp.guard != 0, st, num_cu, cap, keep_max);
-    case 4: return launch_txframe_mid<4>(p, sp.guard != 0, st, num_cu, cap, keep_max);
-    case 8: return launch_txframe_mid<8>(p, sp.guard != 0, st, num_cu, cap, keep_max);
-    case 16: return launch_txframe_mid<16>(p, sp.guard != 0, st, num_cu, cap, keep_max);
-    case 32: return launch_txframe_mid<32>(p, sp.guard != 0, st, num_cu, cap, keep_max);
+    case 1: return launch_txframe_mid<1>(p, sp.guard != 0, st, num_cu, cap, keep_max, rewrite);
+    case 2: return launch_txframe_mid<2>(p, sp.guard != 0, st, num_cu, cap, keep_max, rewrite);
+    case 4: return launch_txframe_mid<4>(p, sp.guard != 0, st, num_cu, cap, keep_max, rewrite);
+    case 8: return launch_txframe_mid<8>(p, sp.guard != 0, st, num_cu, cap, keep_max, rewrite);
+    case 16: return launch_txframe_mid<16>(p, sp.guard != 0, st, num_cu, cap, keep_max, rewrite);
+    case 32: return launch_txframe_mid<32>(p, sp.guard != 0, st, num_cu, cap, keep_max, rewrite);
     }
     return hipErrorNotSupported;
 }

@@ -362,6 +362,7 @@ const TuneKey kTuneKeys[] = {
     {"no_rx1024_finish", &Tuning::no_rx1024_finish, false},
     {"tx_waves", &Tuning::tx_waves, false},
     {"txframe_keep_steps", &Tuning::txframe_keep_steps, false},
+    {"txframe_rewrite", &Tuning::txframe_rewrite, false},
     {"sc_wg_per_cu", &Tuning::sc_wg_per_cu, false},
     {"sc_first_lags", &Tuning::sc_first_lags, false},
     {"sc128_one_wave", &Tuning::sc128_one_wave, false},
