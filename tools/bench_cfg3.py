@@ -130,7 +130,7 @@ def _traffic(kernels):
     for rnd in ("r04", "r03"):
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{rnd}_pmc_traffic.json")
         try:
-            pm = json.load(open(path))
+            pm = json.load(open(path))["per_kernel"]
             tot = 0.0
             for k in kernels:
                 tot += pm[k]["read_bytes_per_frame"] + pm[k].get("write_bytes_per_frame", 0.0)
@@ -224,7 +224,7 @@ def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
            "parity": "64-QAM and the Schmidl-Cox detector are north-star extensions the reference lacks (EXT-1, EXT-3): parity unpinned by "
                      "the reference, the oracle is the definition"}
     blocks, res = chain_block(api, torch, ctx, x, payload, n_frames, steps, grp, W,
-                              traffic_keys=("staged_first_lags_k_sc_cf_128", "k_rxframe64"))
+                              traffic_keys=("k_sc_cf_128_first_lags", "k_rxframe64"))
     out.update(blocks)
     full, bounded, one = res["full"], res["bounded"], res["one"]
     nok, ber = _ber(torch, full, payload)  # this rank's frames (rank 0's in the report)

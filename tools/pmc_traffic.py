@@ -78,6 +78,14 @@ out = {
              "k_tx4096_write_bytes_per_symbol": round(wr("ofdm::k_tx4096<true>") / n5, 1),
              "note": "RX: 4096 x 8 B, the 1024-sample cyclic prefix is never fetched; TX: exactly the 5120-sample symbol is written, the payload (3072 B) read once"},
     "mid_kernels": {},
+    # flat per-kernel view (bytes per frame of the probe's batches) for the bench blocks' `roofline.traffic` (tools/bench_cfg3._traffic)
+    "per_kernel": {
+        "k_sc_cf_128_first_lags": {"read_bytes_per_frame": round(rd("ofdm::k_sc_cf<128, ") / n, 1), "write_bytes_per_frame": round(wr("ofdm::k_sc_cf<128, ") / n, 1)},
+        "k_rxframe64": {"read_bytes_per_frame": round(rd("ofdm::k_rxframe64<6, true>") / n, 1), "write_bytes_per_frame": round(wr("ofdm::k_rxframe64<6, true>") / n, 1),
+                        "note": "8-byte loads at arbitrary sample offsets: FETCH_SIZE under-reports this pattern (it reads below the 10 752 B the kernel needs)"},
+        "k_sc_stream": {"read_bytes_per_frame": round(rd("ofdm::k_sc_stream<2>") / n4, 1), "write_bytes_per_frame": round(wr("ofdm::k_sc_stream<2>") / n4, 1)},
+        "k_rxframe1024": {"read_bytes_per_frame": round(rd("ofdm::k_rxframe1024<6, true>") / n4, 1), "write_bytes_per_frame": round(wr("ofdm::k_rxframe1024<6, true>") / n4, 1)},
+    },
 }
 for nn, r in ((512, 8), (2048, 32)):
     m = info[f"mid_{nn}"]

@@ -32,6 +32,7 @@ for w in sc_every_lag cfg3_chain cfg3_late cfg4_chain cfg4_late cfg5; do
   echo "clean $w done"
 done
 fi
+if [ -n "$SKIP_PMC" ]; then echo "all done (no PMC passes)"; exit 0; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$c -- python3 "$OLDPWD/tools/pmc_probe.py" > "$OUT/${ROUND}_pmc_$c.log" 2>&1 ) || exit 4
   echo "pmc $c done"
