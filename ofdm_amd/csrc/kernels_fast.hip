@@ -414,19 +414,14 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
             for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                // bins t + 8 m of rows 1, 2, 5, 6 are data carriers for every lane (nulls and pilots sit in rows 0, 3, 4, 7): no test
-                // there; in the other rows a lane without a data bin ORs a zero into word 0 instead of branching around the field
-                // (an exec-mask branch per row costs more issue slots than the wasted demap)
-                const bool all_data = !GUARD || m == 1 || m == 2 || m == 5 || m == 6;
-                const int bo_t = bofftab[m * 64 + lane];
-                const bool data = all_data || bo_t >= 0;
-                const int bo = data ? bo_t : 0;
-                const unsigned idx_t = GUARD ? demap_point_rot(v[m], rot, BPS) : demap_point(v[m], BPS);
-                const unsigned idx = data ? idx_t : 0u;
-                const int wd = bo >> 5, sh = bo & 31;
-                atomicOr(&img[wd], idx << sh);
-                if (BPS > 1 && (32 % BPS) != 0) {
-                    if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
+                const int bo = bofftab[m * 64 + lane];
+                if (bo >= 0) {
+                    const unsigned idx = GUARD ? demap_point_rot(v[m], rot, BPS) : demap_point(v[m], BPS);
+                    const int wd = bo >> 5, sh = bo & 31;
+                    atomicOr(&img[wd], idx << sh);
+                    if (BPS > 1 && (32 % BPS) != 0) {
+                        if (sh + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - sh));
+                    }
                 }
             }
             // the next group's samples leave the prefetch registers BEFORE this group's bytes are stored: loads and stores share the

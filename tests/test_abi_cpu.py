@@ -276,3 +276,12 @@ int main() {
     assert len(rows) == 6 * (1 + 2 + 3 + 8)
     for n, w, r, lo, hi in rows:
         assert (lo, hi) == shard_range(n, r, w)
+
+
+def test_rust_binding_text_declares_the_whole_surface():
+    """bindings/ofdm_hip.rs is untested source text (no cargo in this image); at least its extern block must name every function of
+    include/ofdm_hip.h, so that the binding a maintainer copies is not missing an entry point."""
+    rs = open(os.path.join(ROOT, "bindings", "ofdm_hip.rs")).read()
+    declared = set(re.findall(r"pub fn (ofdm_[a-z0-9_]+)\s*\(", rs))
+    missing = [n for n in header_functions() if n not in declared]
+    assert not missing, missing
