@@ -126,7 +126,7 @@ int ofdm_last_hip_error(const ofdm_ctx *ctx); /* raw hipError_t of the last fail
  * one ran.  Returns the full length of the string (like snprintf), buf receives at most n - 1 characters. Host call. */
 int ofdm_last_dispatch(const ofdm_ctx *ctx, char *buf, size_t n);
 /* Per-context tuning: A/B switches between kernel families and grid shapes.  The library reads NO environment variable.
- * Keys (value >= 0): "one_pass_rx" 0/1 (overrides ofdm_params.rx_path), "no_sc_stream", "no_sc_big", "no_rx1024_finish", "no_fast64", "no_demod4096",
+ * Keys (value >= 0): "one_pass_rx" 0/1 (overrides ofdm_params.rx_path), "no_sc_stream", "no_sc_big", "no_rx1024_finish", "no_rxframe64_split" (1: one N = 64 receive kernel with both frame bodies instead of the common-body / cut-body pair), "no_fast64", "no_demod4096",
  * "no_mid_kernels", "no_rxframe1024", "no_txframe64" (1 = take the generic kernel instead of that family), "grid_cap"
  * (> 0: caps every persistent grid -- the tests use it to run many pipeline steps per workgroup on small batches),
  * "tx_waves", "txframe_keep_steps" (1: frames that fit one step of k_txframe_mid are built once; 0: always twice), "txframe_rewrite" (1: longer frames are built once, stored unnormalised and rescaled in a second sweep -- measured slower, A/B only), "sc_wg_per_cu", "sc_first_lags" (N = 64 searches: lags of the first of two launches, 0 = one launch), "sc128_one_wave" (1: one wavefront per frame in the 128-chunk k_sc_cf), "demod64_wg_per_cu", "demod64_burst" (16 / 8 / 4 / 1), "demod64_narrow_stores",

@@ -20,6 +20,7 @@ struct Tuning {
     int no_sc_big = 0;             // long-period Schmidl-Cox through k_sc_tile instead of k_scb_chunks + k_scb_fine
     int no_fast64 = 0, no_demod4096 = 0, no_mid_kernels = 0, no_rxframe1024 = 0, no_txframe64 = 0; // take the generic k_sym
     int no_rx1024_finish = 0;      // k_rxframe1024 writes raw bytes and k_rx_finish runs as its own launch
+    int no_rxframe64_split = 0;    // k_rxframe64 as ONE kernel with both frame bodies (three waves per SIMD) instead of the common-body / cut-body pair (A/B)
     long long grid_cap = 0;        // > 0: caps every persistent grid (test hook: many steps per workgroup on a small batch)
     int tx_waves = 16;             // k_txframe64: wavefronts per CU
     int txframe_keep_steps = 1;    // k_txframe_mid: 1 = frames whose data symbols fit ONE workgroup step (<= 32 / R symbols) are built once, their points kept in registers until the maximum is known; 0 = always twice
@@ -136,9 +137,11 @@ hipError_t run_txframe_mid(int n_fft, const SymParams &p, const float2 *header, 
 // final_out / final_stride / final_len (optional, 4-byte aligned): also do the length-header parse + truncate and write the
 // payload bytes to their final place (no outer code), so that no separate finish kernel is needed
 // frame_list / frame_count (device, optional): only the listed frames are processed
+// cut_ws (device, optional, n_frames + 4 ints): the split form -- one launch with only the common frame body (four waves per SIMD) over
+// every frame, one with only the capture-cut body over the frames the first one left on the list in cut_ws
 hipError_t run_rxframe64(const SymParams &p, float2 *hk_out, hipStream_t st, int num_cu, unsigned char *final_out = nullptr,
                          long long final_stride = 0, int32_t *final_len = nullptr, const int32_t *frame_list = nullptr,
-                         const int32_t *frame_count = nullptr);
+                         const int32_t *frame_count = nullptr, int32_t *cut_ws = nullptr);
 // fused encode for N = 64 (map + IFFT + CP + header + normalise, one HBM pass); hipErrorNotSupported outside its envelope
 hipError_t run_txframe64(const SymParams &p, const float2 *header, float header_max, hipStream_t st, int num_cu);
 

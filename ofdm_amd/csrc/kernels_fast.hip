@@ -231,6 +231,8 @@ struct RxFrame64Params {
     int32_t *final_len;
     const int32_t *frame_list;   // optional: only these frames (count on the device)
     const int32_t *frame_count;
+    int32_t *cut_list;           // MODE 0: frames whose capture ends inside the frame are appended here (count at cut_count) for the MODE 1 launch
+    int32_t *cut_count;
 };
 
 __device__ __forceinline__ cf lane_xor_sum(cf v) { // sum over the 8 symbol slots: lanes with equal (lane & 7)
@@ -240,8 +242,14 @@ __device__ __forceinline__ cf lane_xor_sum(cf v) { // sum over the 8 symbol slot
     return v;
 }
 
-template <int BPS, bool GUARD>
-__global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
+// MODE (round 4): the body exists twice -- for frames that lie wholly inside their capture, and for captures that END inside the
+// frame (zero-filled tail, pad_chunk) -- and with both in one kernel the register budget is the larger one's: 168 VGPRs, three
+// waves per SIMD.  MODE 0 holds only the common body (126 VGPRs with guard bands: FOUR waves per SIMD -- the kernel is VALU-issue
+// bound and three waves cannot fill the pipe) and appends the frames it has to leave to a device-side list; MODE 1
+// holds only the cut body and runs over that list (normally empty: microseconds); MODE 2 is the round-3 kernel with both bodies,
+// for callers that bring their own frame list (the one-pass kernel's slow list).
+template <int BPS, bool GUARD, int MODE>
+__global__ __launch_bounds__(256, (MODE == 0 && GUARD) ? 4 : 3) void k_rxframe64(RxFrame64Params p) {
     constexpr int S = 80, CP = 16;
     constexpr int ND = GUARD ? 48 : 64;
     constexpr int SYM_BYTES = ND * BPS / 8;   // multiple of 4 (checked by the launcher)
@@ -273,8 +281,18 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
             bofftab[m * 64 + lane] = (carrier_class64(c, GUARD) == 0) ? (s * ND + q) * BPS : -1;
         }
     }
+    __shared__ int cutbuf[4][1 + 16];         // MODE 0: per wavefront, the cut frames not yet on the global list (batched: one atomic per 16)
+    if (MODE == 0 && lane == 0) cutbuf[wave][0] = 0;
     __syncthreads();
     const int wr = swz(8 * t);
+    auto cut_flush = [&]() { // lane 0 only; this wavefront's own slots: no other wavefront reads or writes them
+        const int m = cutbuf[wave][0];
+        if (m > 0) {
+            const int base = atomicAdd(p.cut_count, m);
+            for (int i = 0; i < m; ++i) p.cut_list[base + i] = cutbuf[wave][1 + i];
+            cutbuf[wave][0] = 0;
+        }
+    };
 
     const long long n_items = p.frame_list ? (long long)*p.frame_count : p.n_frames;
     // The per-frame scalars (live symbols, offset, CFO) of the NEXT frame of this wavefront are fetched while the current frame is
@@ -452,19 +470,44 @@ __global__ __launch_bounds__(256, 3) void k_rxframe64(RxFrame64Params p) {
             }
         }
         };
-        if ((long long)(10 + ns) * S <= avail) frame_body(std::false_type{}); else frame_body(std::true_type{}); // wave-uniform
+        const bool whole = (long long)(10 + ns) * S <= avail; // wave-uniform
+        if (MODE == 0) {
+            if (whole) frame_body(std::false_type{});
+            else if (lane == 0) { // left to the MODE 1 launch
+                const int m = cutbuf[wave][0];
+                cutbuf[wave][1 + m] = (int32_t)f;
+                cutbuf[wave][0] = m + 1;
+                if (m + 1 == 16) cut_flush();
+            }
+        } else if (MODE == 1) {
+            if (!whole) frame_body(std::true_type{});
+        } else {
+            if (whole) frame_body(std::false_type{}); else frame_body(std::true_type{});
+        }
     }
+    if (MODE == 0 && lane == 0) cut_flush();
 }
 
-template <int BPS> static hipError_t launch_rxframe(const RxFrame64Params &p, bool guard, dim3 grid, hipStream_t st) {
-    if (guard) hipLaunchKernelGGL((k_rxframe64<BPS, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_rxframe64<BPS, false>), grid, dim3(256), 0, st, p);
+template <int BPS, int MODE> static void launch_rxframe_m(const RxFrame64Params &p, bool guard, dim3 grid, hipStream_t st) {
+    if (guard) hipLaunchKernelGGL((k_rxframe64<BPS, true, MODE>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_rxframe64<BPS, false, MODE>), grid, dim3(256), 0, st, p);
+}
+// split = the caller gave a cut-list workspace and no frame list of its own: MODE 0 over every frame, then MODE 1 over the frames it left
+template <int BPS> static hipError_t launch_rxframe(RxFrame64Params p, bool guard, dim3 grid, hipStream_t st, bool split) {
+    if (!split) { launch_rxframe_m<BPS, 2>(p, guard, grid, st); return hipGetLastError(); }
+    hipError_t e = hipMemsetAsync(p.cut_count, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
+    launch_rxframe_m<BPS, 0>(p, guard, grid, st);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    p.frame_list = p.cut_list; p.frame_count = p.cut_count;
+    launch_rxframe_m<BPS, 1>(p, guard, grid, st); // the same persistent grid: a batch of captures that are ALL cut short must not crawl through 64 workgroups (an empty list costs microseconds either way)
     return hipGetLastError();
 }
 
 // Fused channel estimate + demod for N = 64 frames.  hipErrorNotSupported => caller uses run_chest + run_demod.
 hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, int num_cu, unsigned char *final_out,
-                         long long final_stride, int32_t *final_len, const int32_t *frame_list, const int32_t *frame_count) {
+                         long long final_stride, int32_t *final_len, const int32_t *frame_list, const int32_t *frame_count,
+                         int32_t *cut_ws) {
     const int nd = sp.guard ? 48 : 64;
     if ((nd * sp.bps / 8) % 4 != 0 || !sp.nsym_frame || sp.soft) return hipErrorNotSupported;
     if ((reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
@@ -478,16 +521,23 @@ hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, in
         p.final_out = final_out; p.final_stride = final_stride; p.final_len = final_len;
     } else if (final_out) return hipErrorNotSupported;
     p.frame_list = frame_list; p.frame_count = frame_count;
+    // The split pays when cut captures are the exception (measured on 1 M config-3 frames, same box: chain 4.98 -> 4.68 ms / 4.98 -> 4.88 ms on
+    // two boxes; with EVERY capture cut short the pair costs 18 % more than the one kernel: a skip pass plus the list): it is used when the
+    // capture has room for the longest frame the caller asks for plus a 64-sample start offset -- what a slotted capture looks like.
+    const bool roomy = sp.frame_len >= (long long)(10 + sp.syms_per_frame) * 80 + 64;
+    const bool split = cut_ws != nullptr && frame_list == nullptr && roomy && !tuning_or_default(sp.tune).no_rxframe64_split;
+    p.cut_count = split ? cut_ws : nullptr; p.cut_list = split ? cut_ws + 4 : nullptr;
     long long blocks = (sp.n_frames + 3) / 4, cap = frame_list ? 64 : (long long)num_cu * 8;
     { const long long gc = tuning_or_default(sp.tune).grid_cap; if (gc > 0 && gc < cap) cap = gc; }
     const dim3 grid((unsigned)(blocks < cap ? blocks : cap));
     trace_add(sp.trace, frame_list ? "k_rxframe64<list>" : (p.final_out ? "k_rxframe64<finish>" : "k_rxframe64"));
+    if (split) trace_add(sp.trace, "k_rxframe64<cut,list>");
     switch (sp.bps) {
-    case 2: return launch_rxframe<2>(p, sp.guard != 0, grid, st);
-    case 4: return launch_rxframe<4>(p, sp.guard != 0, grid, st);
-    case 6: return launch_rxframe<6>(p, sp.guard != 0, grid, st);
-    case 8: return launch_rxframe<8>(p, sp.guard != 0, grid, st);
-    case 1: if (!sp.guard) return launch_rxframe<1>(p, false, grid, st); return hipErrorNotSupported;
+    case 2: return launch_rxframe<2>(p, sp.guard != 0, grid, st, split);
+    case 4: return launch_rxframe<4>(p, sp.guard != 0, grid, st, split);
+    case 6: return launch_rxframe<6>(p, sp.guard != 0, grid, st, split);
+    case 8: return launch_rxframe<8>(p, sp.guard != 0, grid, st, split);
+    case 1: if (!sp.guard) return launch_rxframe<1>(p, false, grid, st, split); return hipErrorNotSupported;
     default: return hipErrorNotSupported;
     }
 }

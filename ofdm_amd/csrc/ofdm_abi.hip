@@ -360,6 +360,7 @@ const TuneKey kTuneKeys[] = {
     {"no_rxframe1024", &Tuning::no_rxframe1024, false},
     {"no_txframe64", &Tuning::no_txframe64, false},
     {"no_rx1024_finish", &Tuning::no_rx1024_finish, false},
+    {"no_rxframe64_split", &Tuning::no_rxframe64_split, false},
     {"tx_waves", &Tuning::tx_waves, false},
     {"txframe_keep_steps", &Tuning::txframe_keep_steps, false},
     {"txframe_rewrite", &Tuning::txframe_rewrite, false},
@@ -921,10 +922,13 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
         p.in = x; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
         p.offset = offs; p.f_delta = fd; p.nsym_frame = (const int32_t *)w_nsym;
         p.out_bytes = (uint8_t *)w_raw; p.out_stride = raw_stride;
+        p.syms_per_frame = max_symbols; // (the launcher's "is there room for a whole frame in the capture" test)
         // without an outer code the kernel also parses the length header and writes the payload to its final place
         const bool fin = c->prm.ecc == OFDM_ECC_NONE && (reinterpret_cast<uintptr_t>(out) & 3) == 0 && (out_stride & 3) == 0;
-        hipError_t e = fin ? run_rxframe64(p, nullptr, c->stream, c->num_cu, out, out_stride, out_len)
-                           : run_rxframe64(p, nullptr, c->stream, c->num_cu);
+        void *w_cut;
+        if ((rc = ws_get(c, 8, sizeof(int32_t) * (size_t)(n_frames + 4), &w_cut))) return rc;
+        hipError_t e = fin ? run_rxframe64(p, nullptr, c->stream, c->num_cu, out, out_stride, out_len, nullptr, nullptr, (int32_t *)w_cut)
+                           : run_rxframe64(p, nullptr, c->stream, c->num_cu, nullptr, 0, nullptr, nullptr, nullptr, (int32_t *)w_cut);
         if (e == hipSuccess) { fused = true; finished = fin; }
         else if (e != hipErrorNotSupported) { c->last_hip = (int)e; return OFDM_ERR_HIP; }
     }

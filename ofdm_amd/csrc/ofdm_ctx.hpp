@@ -30,7 +30,7 @@ struct ofdm_ctx {
     ofdm::Trace trace;                  // ofdm_last_dispatch: the kernels the last entry point launched
     ofdm::ScStats sc_stats;             // list counters of the last Schmidl-Cox search (ofdm_get_tuning "stat_sc_*")
     // workspaces (grown on demand, never inside a captured region)
-    Workspace ws[8];
+    Workspace ws[10];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     HostPipe *pipe = nullptr;     // created by the first host-buffer call, freed by ofdm_destroy
 

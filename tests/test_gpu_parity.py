@@ -737,6 +737,49 @@ def test_rx_decode_batch_variants(api, orc, n, mod, guard, ecc, nbytes, cfo_abs)
     assert errs / (6 * nbytes * 8) < 5e-3
 
 
+@pytest.mark.parametrize("mod,guard,grid_cap", [(6, True, 0), (6, True, 3), (2, False, 2), (4, True, 0)])
+def test_rxframe64_common_and_cut_bodies_as_two_launches(api, orc, mod, guard, grid_cap):
+    """Round 4: k_rxframe64 runs as a pair -- the common frame body alone (four waves per SIMD with guard bands) over every frame,
+    the capture-cut body over the device-side list of the frames the first launch had to leave.  Roomy captures (room for a whole
+    frame + 64 samples) in which SOME frames start so late that the capture ends inside their data symbols, a noise-only slot and a
+    slot too short to decode: status, offset, CFO, length and bytes must equal the oracle's and the one-kernel form's
+    (tuning no_rxframe64_split), with the list walked by a capped grid as well."""
+    rng = np.random.default_rng(64 + mod + grid_cap)
+    nbytes = {6: 560, 2: 230, 4: 360}[mod]
+    tune = {"grid_cap": grid_cap} if grid_cap else {}
+    ctx = api.Context(n_fft=64, modulation=mod, guard_bands=guard, tuning=tune)
+    one = api.Context(n_fft=64, modulation=mod, guard_bands=guard, tuning={**tune, "no_rxframe64_split": 1})
+    flen, D = ctx.frame_samples(nbytes), ctx.data_symbols(nbytes)
+    span = flen + 64 + 40
+    nfr = 37
+    delays = [int(rng.integers(1, 60)) if f % 3 else int(rng.integers(110, 700)) for f in range(nfr)]   # every third frame is cut
+    caps = []
+    for f in range(nfr):
+        tx = orc.encode(bytes(rng.integers(0, 256, nbytes, dtype=np.uint8)), guard, mod, 64)
+        caps.append(through_channel(orc, rng, tx, span, delays[f], (rng.random() * 1.8 - 0.9) * np.pi / 80, 30.0, data_start=800))
+    caps[5] = fc32(0.003 * (rng.standard_normal(span) + 1j * rng.standard_normal(span)))                 # nothing to find
+    caps = np.stack(caps)
+    ra = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=D).items()}
+    assert ctx.last_dispatch().endswith("k_rxframe64<finish>+k_rxframe64<cut,list>"), ctx.last_dispatch()
+    rb = {k: host(v) for k, v in one.decode_batch(dev(one, caps), max_symbols=D).items()}
+    assert one.last_dispatch().endswith("k_rxframe64<finish>"), one.last_dispatch()
+    n_cut = 0
+    for f in range(nfr):
+        w = orc.decode_sc(wide(caps[f]), guard, mod, 64, max_symbols=D)
+        assert ra["status"][f] == rb["status"][f] == w["status"], f
+        if w["status"] != 0:
+            assert ra["len"][f] == rb["len"][f] == 0
+            continue
+        assert ra["offset"][f] == rb["offset"][f] == w["offset"] and abs(ra["f_delta"][f] - w["f_delta"]) <= 1e-9
+        assert ra["len"][f] == rb["len"][f] == len(w["bytes"])
+        got = bytes(ra["bytes"][f][: ra["len"][f]])
+        assert got == bytes(rb["bytes"][f][: rb["len"][f]]), f       # the two forms agree bit for bit
+        n_cut += (10 + D) * 80 > span - w["offset"]
+        if got != w["bytes"]:                                          # a decision on the oracle's own boundary (never seen on these seeds)
+            assert sum(a != b for a, b in zip(got, w["bytes"])) <= 1, f
+    assert n_cut >= 8 and (ra["status"] == 0).sum() >= nfr - 3          # the cut body did run, on several frames
+
+
 @pytest.mark.parametrize("n,mod,guard", [(1024, 4, True), (1024, 6, False), (64, 6, True)])
 def test_rx_decode_truncated_and_limited(api, orc, n, mod, guard):
     """The fused per-frame kernels (k_rxframe64 / k_rxframe1024) on captures that END inside a data symbol (pad_chunk,
