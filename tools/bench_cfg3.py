@@ -75,7 +75,7 @@ def required_sync_bytes(torch, d_hat, span, W, L):
     return int(need.sum()) * 8
 
 
-def cpu_leg(x, payload, gpu, D, n_sample, threads):
+def cpu_leg(x, payload, gpu, D, n_sample, threads, span=SPAN, target_s=3.0):
     """oracle decode_sc (all lags) on the first n_sample frames, all cores; per-frame equality with the GPU's outputs."""
     from oracle import oracle as orc
     from tools import cpu_baseline as cb
@@ -89,7 +89,7 @@ def cpu_leg(x, payload, gpu, D, n_sample, threads):
     def work(frames):
         return [orc.decode_sc(f, True, orc.QAM64, 64, max_symbols=D) for f in frames]
 
-    rec, outs = cb.timed(work, wide, n_sample * SPAN / 1e6, target_s=3.0)
+    rec, outs = cb.timed(work, wide, n_sample * span / 1e6, target_s=target_s)
     st = gpu["status"][:n_sample].cpu().numpy(); off = gpu["offset"][:n_sample].cpu().numpy()
     ln = gpu["len"][:n_sample].cpu().numpy(); by = gpu["bytes"][:n_sample].cpu().numpy()
     pay = payload[:n_sample].cpu().numpy()
@@ -263,7 +263,11 @@ def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
     xl, pl = synth(api, torch, ctx, n_frames, span=LATE_SPAN, seed=31 + rank, max_delay=late_delay, noise_only=LATE_NOISE_ONLY)
     lblocks, lres = chain_block(api, torch, ctx, xl, pl, n_frames, steps, grp, W, name_suffix="_late_packets", one_pass=False, span=LATE_SPAN)
     nok_l, ber_l = _ber(torch, lres["full"], pl)
-    out["late_packets"] = {"workload": f"the same frames in {LATE_SPAN}-sample slots, delay uniform over 1..{late_delay}, "
+    late_cpu = None
+    if cpu and rank == 0:  # the oracle on a sample of the late / empty slots: the placements round 3's f32 filter sent to the all-f64 kernel
+        from tools import cpu_baseline as cb
+        late_cpu = cpu_leg(xl, pl, lres["full"], D, min(n_frames, 16384), cb.host_threads(), span=LATE_SPAN, target_s=1.5)
+    out["late_packets"] = {"cpu_check": late_cpu,"workload": f"the same frames in {LATE_SPAN}-sample slots, delay uniform over 1..{late_delay}, "
                                        f"{int(LATE_NOISE_ONLY * 100)} % of the slots noise only",
                            "frames_decoded": nok_l, "ber_decoded_frames_vs_tx_payload": ber_l, **lblocks}
     return out

@@ -232,8 +232,21 @@ def cfg4(n_frames=65536, total_frames=10_000_000, cpu=True, snr_db=40.0, grp=Non
     #     without a packet; a few passes are enough for a rate
     late_span = flen + 4096 + 256
     xl, pl = _cfg4_ring(ctx, g, n_frames, late_span, snr_db, rank, max_delay=4096, noise_only=0.10)
-    lblk, _ = block(xl, pl, late_span, min(passes, 8), (("full_chain_all_lags_late_packets", 0),))
-    res["late_packets"] = {"workload": f"the same frames in {late_span}-sample slots, delay uniform over 1..4096, 10 % of the slots noise only", **lblk}
+    lblk, lfull = block(xl, pl, late_span, min(passes, 8), (("full_chain_all_lags_late_packets", 0),))
+    late_cpu = None
+    if cpu and rank == 0:  # the oracle on the first 256 late / empty slots
+        from oracle import oracle as orc
+        orc.lib(); orc.set_fft_cache(True)
+        xs = xl[:256].cpu().numpy()
+        st = lfull["status"][:256].cpu().numpy(); off = lfull["offset"][:256].cpu().numpy()
+        ln = lfull["len"][:256].cpu().numpy(); by = lfull["bytes"][:256].cpu().numpy()
+        same = 0
+        for j in range(256):
+            w = orc.decode_sc(xs[j].astype(np.complex128), True, orc.QAM64, 1024, max_symbols=D)
+            same += int(st[j] == w["status"] and (w["status"] != 0 or (off[j] == w["offset"] and bytes(by[j][: ln[j]]) == orc.hamming74_decode(w["bytes"])[0])))
+        orc.set_fft_cache(False)
+        late_cpu = {"frames_compared": 256, "frames_identical_to_gpu": same, "gpu_bytes_equal_cpu_bytes": same == 256}
+    res["late_packets"] = {"cpu_check": late_cpu,"workload": f"the same frames in {late_span}-sample slots, delay uniform over 1..4096, 10 % of the slots noise only", **lblk}
     return res
 
 
