@@ -54,15 +54,15 @@ out = {
     "cfg3": {"frames": n, "capture_bytes_per_frame": cap3,
              "every_lag_k_sc_cf_256_read_bytes_per_frame": round(rd_max("ofdm::k_sc_cf<256, 2, 4, 0, false>") / n, 1),
              "staged_first_lags_k_sc_cf_128_read_bytes_per_frame": round(rd("ofdm::k_sc_cf<128, ") / n, 1),
-             "staged_k_rxframe64_read_bytes_per_frame": round(rd("ofdm::k_rxframe64<6, true>") / n, 1),
+             "staged_k_rxframe64_read_bytes_per_frame": round(rd("ofdm::k_rxframe64<6, true, 0>") / n, 1),
              "staged_k_rxframe64_needed_bytes_per_frame": 21 * 512,
              "one_pass_k_sc_cf_read_bytes_per_frame": round(rd("ofdm::k_sc_cf<256, 2, 3, 6, true>") / n, 1),
              "one_pass_write_bytes_per_frame": round(wr("ofdm::k_sc_cf<256, 2, 3, 6, true>") / n, 1),
              "k_txframe64_read_bytes_per_frame": round(rd("ofdm::k_txframe64<6, true>") / n, 1),
              "k_txframe64_write_bytes_per_frame": round(wr("ofdm::k_txframe64<6, true>") / n, 1),
              "note": "the product's search reads the first 384 + W + L samples of a slot (k_sc_cf<128>) and the whole slot only for frames those "
-                     "lags do not determine; k_rxframe64 loads 8 B per lane at arbitrary sample offsets and FETCH_SIZE under-reports that "
-                     "pattern (it reads below the 10752 B the kernel needs), so the staged chain is claimed at first-lags bytes + 10752 B per frame"},
+                     "lags do not determine; k_rxframe64 loads 8 B per lane at arbitrary sample offsets (FETCH_SIZE is not reliable for that "
+                     "pattern: 6.8 KB in round 3, 14.9 KB in round 4 for the same 10752 B needed), so the staged chain is claimed at first-lags bytes + 10752 B per frame"},
     "cfg4": {"frames": n4, "capture_bytes_per_frame": cap4, "search": "every lag",
              "k_sc_stream_read_bytes_per_frame": round(rd("ofdm::k_sc_stream<2>") / n4, 1),
              "k_rxframe1024_read_bytes_per_frame": round(rd("ofdm::k_rxframe1024<6, true>") / n4, 1),
@@ -81,8 +81,8 @@ out = {
     # flat per-kernel view (bytes per frame of the probe's batches) for the bench blocks' `roofline.traffic` (tools/bench_cfg3._traffic)
     "per_kernel": {
         "k_sc_cf_128_first_lags": {"read_bytes_per_frame": round(rd("ofdm::k_sc_cf<128, ") / n, 1), "write_bytes_per_frame": round(wr("ofdm::k_sc_cf<128, ") / n, 1)},
-        "k_rxframe64": {"read_bytes_per_frame": round(rd("ofdm::k_rxframe64<6, true>") / n, 1), "write_bytes_per_frame": round(wr("ofdm::k_rxframe64<6, true>") / n, 1),
-                        "note": "8-byte loads at arbitrary sample offsets: FETCH_SIZE under-reports this pattern (it reads below the 10 752 B the kernel needs)"},
+        "k_rxframe64": {"read_bytes_per_frame": round(rd("ofdm::k_rxframe64<6, true, 0>") / n, 1), "write_bytes_per_frame": round(wr("ofdm::k_rxframe64<6, true, 0>") / n, 1),
+                        "note": "8-byte loads at arbitrary sample offsets: a 512-byte symbol that starts anywhere touches five 128-byte lines (640 B), so 21 symbols fetch up to 13.4 KB for the 10 752 B the kernel needs; round 3's three-waves-per-SIMD kernel showed 6.8 KB here (FETCH_SIZE is not reliable for this pattern)"},
         "k_sc_stream": {"read_bytes_per_frame": round(rd("ofdm::k_sc_stream<2>") / n4, 1), "write_bytes_per_frame": round(wr("ofdm::k_sc_stream<2>") / n4, 1)},
         "k_rxframe1024": {"read_bytes_per_frame": round(rd("ofdm::k_rxframe1024<6, true>") / n4, 1), "write_bytes_per_frame": round(wr("ofdm::k_rxframe1024<6, true>") / n4, 1)},
     },
