@@ -269,6 +269,39 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 
+// Totals of FOUR f64 values over the wavefront, every lane receiving all four -- a transpose-reduce instead of four scans: the first
+// two steps trade values between lane pairs (lane ^ 1: even lanes keep a and c, odd lanes b and d; lane ^ 2: one value per lane,
+// quantity = lane & 3), two row rotations add the four lanes of a row that hold the same quantity, and gfx950's
+// v_permlane16_swap / v_permlane32_swap add the rows.  Eight 64-bit additions and 14 lane movements instead of 24 and 48.
+template <int CTRL> __device__ __forceinline__ double dpp_q(double x) { // quad / row permutation of a double, every lane valid
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rows_sum16(double x) { // [r0, r1, r2, r3] -> [r0 + r1, r0 + r1, r2 + r3, r2 + r3], lane for lane
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double halves_sum32(double x) { // [lower, upper] -> lower + upper in both halves, lane for lane
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void wave_sum4(double &a, double &b, double &c, double &d, int lane) {
+    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+    double k0 = o1 ? b : a, k1 = o1 ? d : c;            // kept; the partner receives the other two
+    k0 += dpp_q<0xB1>(o1 ? a : b);                       // quad_perm [1,0,3,2]: lane ^ 1
+    k1 += dpp_q<0xB1>(o1 ? c : d);
+    double k = o2 ? k1 : k0;
+    k += dpp_q<0x4E>(o2 ? k0 : k1);                      // quad_perm [2,3,0,1]: lane ^ 2 -> quantity (lane & 3) summed over the quad
+    k += dpp_q<0x124>(k);                                // row_ror:4
+    k += dpp_q<0x128>(k);                                // row_ror:8 -> ... over the row
+    k = halves_sum32(rows_sum16(k));                     // ... over the wavefront
+    a = readlane_d(k, 0); b = readlane_d(k, 1); c = readlane_d(k, 2); d = readlane_d(k, 3);
+}
+
 // Receive body fused behind the timing search (k_sc_cf<..., BPS != 0>): what k_sc_post + k_rx_prepare + k_rxframe64 +
 // k_rx_finish do in four more launches and a second HBM pass, done from the frame's LDS image.
 struct ScRxParams {
@@ -383,8 +416,7 @@ __device__ __forceinline__ Cand sc_exact_pick(const cf *raw, int c0, int c1, int
             xe += ar * ar + ai * ai;
             xq += br * br + bi * bi;
         }
-        xr = readlane_d(wave_scan(xr), 63); xi = readlane_d(wave_scan(xi), 63);
-        xe = readlane_d(wave_scan(xe), 63); xq = readlane_d(wave_scan(xq), 63);
+        wave_sum4(xr, xi, xe, xq, lane);
         const double xn = xr * xr + xi * xi, xd = xe * xq;
         if (xd > 0.0) { // first maximum wins: strictly greater replaces, ties go to the lower lag
             const double lhs = xn * best.den, rhs = best.num * xd;
