@@ -433,15 +433,16 @@ def test_sc_correlate_two_launch_search_equals_the_whole_search(api, orc, reps):
             assert (d_hat == ref[0]).all() and (f_delta == ref[1]).all() and (metric == ref[2]).all(), f"first = {first}"
     # the decode chain takes the same path
     res = []
-    for first in (0, 384):
+    for first in (0, 384, 576):
         ctx = api.Context(modulation=api.QAM64, guard_bands=True, sync_window_reps=reps, tuning={"sc_first_lags": first})
         r = ctx.decode_batch(dev(ctx, caps), max_symbols=8)
         assert ("k_sc_cf<128,first>+k_sc_cf<256,list>" in ctx.last_dispatch()) == (first > 0), ctx.last_dispatch()
         res.append({k: host(v) for k, v in r.items()})
-    for k in ("status", "offset", "len", "f_delta"):
-        assert (res[0][k] == res[1][k]).all(), k
-    for f in range(caps.shape[0]):   # rows are defined up to the frame's length only
-        assert (res[0]["bytes"][f, : res[0]["len"][f]] == res[1]["bytes"][f, : res[1]["len"][f]]).all(), f
+    for other in res[1:]:
+        for k in ("status", "offset", "len", "f_delta"):
+            assert (res[0][k] == other[k]).all(), k
+        for f in range(caps.shape[0]):   # rows are defined up to the frame's length only
+            assert (res[0]["bytes"][f, : res[0]["len"][f]] == other["bytes"][f, : other["len"][f]]).all(), f
     assert int((res[0]["status"][:20] == 0).sum()) >= 18
 
 

@@ -189,7 +189,7 @@ def chain_block(api, torch, ctx, x, payload, n_frames, steps, grp, W_, name_suff
         res["one"] = leg("full_chain_all_lags_one_pass_kernel", 0, True)
     # --- Schmidl-Cox alone over every lag of every slot: (a) the kernel that COMPUTES every lag (one launch, tuning sc_first_lags = 0:
     #     the north-star kernel against the HBM roofline, bytes = the whole slot, which it does read), (b) the product path: the first
-    #     384 lags decide every frame whose crossing and peak window lie among them, the rest take the whole search (same results)
+    #     576 lags decide every frame whose crossing and peak window lie among them, the rest take the whole search (same results)
     sc_slot = n_frames * (span * 8 + 16)
     first = ctx.get_tuning("sc_first_lags")
     for name, fl in (("schmidl_cox", 0), ("schmidl_cox_two_launches", first)):

@@ -26,7 +26,7 @@ for _ in range(2):
     ctx.rx_demod(x2, syms_per_frame=16, out=out2)
     ctx.set_tuning("sc_first_lags", 0)
     ctx.sc_correlate(x3)                     # the kernel that computes every lag: k_sc_cf<256,2,4,0> over every frame
-    ctx.set_tuning("sc_first_lags", 384)
+    ctx.set_tuning("sc_first_lags", 576)
     ctx.decode_batch(x3, max_symbols=16)     # product path: k_sc_cf<128,1,5,0> over the first lags + k_sc_cf<256,2,4,0> over the (empty) list
     ctx.set_tuning("one_pass_rx", 1)
     ctx.decode_batch(x3, max_symbols=16)

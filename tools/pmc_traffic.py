@@ -60,7 +60,7 @@ out = {
              "one_pass_write_bytes_per_frame": round(wr("ofdm::k_sc_cf<256, 2, 3, 6, true>") / n, 1),
              "k_txframe64_read_bytes_per_frame": round(rd("ofdm::k_txframe64<6, true>") / n, 1),
              "k_txframe64_write_bytes_per_frame": round(wr("ofdm::k_txframe64<6, true>") / n, 1),
-             "note": "the product's search reads the first 384 + W + L samples of a slot (k_sc_cf<128>) and the whole slot only for frames those "
+             "note": "the product's search reads the first 576 + W + L samples of a slot (k_sc_cf<128>) and the whole slot only for frames those "
                      "lags do not determine; k_rxframe64 loads 8 B per lane at arbitrary sample offsets (FETCH_SIZE is not reliable for that "
                      "pattern: 6.8 KB in round 3, 14.9 KB in round 4 for the same 10752 B needed), so the staged chain is claimed at first-lags bytes + 10752 B per frame"},
     "cfg4": {"frames": n4, "capture_bytes_per_frame": cap4, "search": "every lag",
