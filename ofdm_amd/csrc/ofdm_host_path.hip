@@ -263,7 +263,10 @@ struct EncodeJob : PipeJob {
     size_t out_bytes(int64_t k) const override { return (size_t)m(k) * (size_t)frame * sizeof(ofdm_fc32); }
     void fill_in(int64_t k, void *p) const override { // [lens | rows of payload_bytes]: a row is read for its own length only
         char *b = static_cast<char *>(p);
-        if (lens) std::memcpy(b, lens + f0(k), 4 * (size_t)m(k));
+        if (lens) { // clamped to the row the library stages: a length beyond payload_bytes must not walk into the next row
+            int32_t *dl = reinterpret_cast<int32_t *>(b);
+            for (int64_t f = 0; f < m(k); f++) dl[f] = std::min<int32_t>(std::max<int32_t>(lens[f0(k) + f], 0), payload_bytes);
+        }
         b += lens_bytes(k);
         for (int64_t f = 0; f < m(k); f++) {
             int64_t n = lens ? lens[f0(k) + f] : payload_bytes;
