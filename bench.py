@@ -252,8 +252,11 @@ def main():
     syms = 16
     ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True, device=local)
     F = a.frames
-    x, payload = synth_cfg2(ctx, torch, F, syms, a.snr_db, seed=rank)
+    # (The kernel's time depends on WHICH allocation it stores to -- tools/out_alloc_probe.py: six output buffers in one process give 1.57
+    # or 1.73 ms per 1 M frames, the same value for a buffer in every round -- and allocating the rows first or last does not change
+    # the odds: about one process in four gets a slow one.  The bench takes the buffer it gets.  DESIGN.md 6.0.)
     out = torch.empty((F, syms * ctx.bytes_per_symbol), dtype=torch.uint8, device=ctx.device)
+    x, payload = synth_cfg2(ctx, torch, F, syms, a.snr_db, seed=rank)
 
     def step():
         ctx.rx_demod(x, syms_per_frame=syms, out=out)
