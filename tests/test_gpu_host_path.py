@@ -180,6 +180,23 @@ def test_decode_long_other_lengths_and_reference_sync(api, orc):
         ref.decode_long(x, 30, lag_lo=100)
 
 
+def test_decode_long_with_the_reference_symbol_count(api, orc):
+    """The reference demodulates EVERY chunk from the trimmed start to the end of the capture and lets the length header truncate
+    (src/receiver.rs:54-95); max_symbols = None asks for exactly that ((n + S - 1) / S - 10 symbols: 1 240 here).  Device and host
+    entry points against the oracle with no symbol limit, and the C-level free function `api.decode` on the same capture."""
+    rng = np.random.default_rng(808)
+    n = 100_000
+    for mod, guard, nbytes, st in ((api.QAM64, True, 560, 30_011), (api.QPSK, False, 400, 77_000)):
+        cap, pays = _capture(orc, rng, n, [st], mod=mod, guard=guard, nbytes=nbytes)
+        want = orc.decode_sc(wide(cap), guard, mod, 64)           # max_symbols = 0: every symbol the capture holds
+        assert want["status"] == 0 and len(want["bytes"]) == nbytes
+        got = api.decode_long(cap, guard, mod)
+        _same_decode(got, want, ("device", mod))
+        ctx = api.Context(n_fft=64, modulation=mod, guard_bands=guard)
+        _same_decode(ctx.decode_long_host(cap, (n + 79) // 80 - 10), want, ("host", mod))
+        assert api.decode(cap, guard, mod) == want["bytes"]
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 def test_host_pipelines_equal_the_device_entry_points(api, orc, pinned):
     """ofdm_rx_decode_host / ofdm_rx_demod_host / ofdm_tx_encode_host == the device-buffer calls they wrap, byte for byte:
