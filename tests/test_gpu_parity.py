@@ -1738,3 +1738,12 @@ def test_cpp_host_loopback(ofdm):
         for extra in ([], ["--start", "1000", "--stop", "4700"]):
             r = subprocess.run([exe, "--receive", cpath] + extra, capture_output=True, text=True, timeout=120)
             assert r.returncode == 0 and "received 400 bytes" in r.stdout, (extra, r.stdout)
+        # a long capture file (the 2 M-sample buffers of examples/jetson_rx.rs, here 600 000 samples with the frame at 412 345): the C++
+        # host's decode goes through ofdm_rx_decode_long_host, i.e. the slice search
+        rng = np.random.default_rng(1)
+        long_cap = (rng.standard_normal((600_000, 2)) * 1e-3).astype(np.float32)
+        long_cap[412_345:412_345 + tx.shape[0]] += tx
+        lpath = os.path.join(td, "long.fc32")
+        long_cap.tofile(lpath)
+        r = subprocess.run([exe, "--receive", lpath], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "received 400 bytes" in r.stdout, r.stdout
