@@ -41,12 +41,23 @@ if which in ("sc_every_lag", "cfg3_chain", "cfg3_late"):
                                 noise_only=bench_cfg3.LATE_NOISE_ONLY)
     else:
         x, _ = bench_cfg3.synth(api, torch, ctx, n, seed=3)
+    span = int(x.shape[1])
     if which == "sc_every_lag":
         ctx.set_tuning("sc_first_lags", 0)
         out["ms"] = timed(ctx, lambda: ctx.sc_correlate(x))
+        disp = ctx.last_dispatch()
+        out["bytes_per_frame"] = span * 8 + 16                      # every lag is computed: the whole slot
     else:
         out["ms"] = timed(ctx, lambda: ctx.decode_batch(x, max_symbols=16))
-    out.update(frames=n, slot_samples=int(x.shape[1]), dispatch=ctx.last_dispatch())
+        disp = ctx.last_dispatch()
+        d_all, _, _ = ctx.sc_correlate(x)                            # (one more, untimed search: d_hat for the required-bytes count)
+        L, W = ctx.S, ctx.params.sync_window_reps * ctx.S
+        found = int((d_all >= 0).sum())
+        out["required_bytes_per_frame"] = (bench_cfg3.required_sync_bytes(torch, d_all, span, W, L) + found * ((5 + 16) * 64 * 8 + bench_cfg3.NBYTES)) / n
+        out["bytes_per_frame"] = out["required_bytes_per_frame"]
+        out["capture_throughput_of_hbm_peak"] = n * (span * 8 + bench_cfg3.NBYTES) / (out["ms"] / 1e3) / 8e12
+    out["roofline_frac"] = n * out["bytes_per_frame"] / (out["ms"] / 1e3) / 8e12   # of 8 TB/s, on the bytes above (tools/bench_cfg3.py's definition)
+    out.update(frames=n, slot_samples=span, dispatch=disp)
 elif which in ("cfg4_chain", "cfg4_late"):
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
     ctx = api.Context(n_fft=1024, modulation=api.QAM64, guard_bands=True, ecc=api.ECC_HAMMING74)
@@ -58,7 +69,15 @@ elif which in ("cfg4_chain", "cfg4_late"):
         x, _ = bench_large_n._cfg4_ring(ctx, g, n, flen + 256, 40.0, 0)
     D = ctx.data_symbols(bench_large_n.CFG4_NBYTES)
     out["ms"] = timed(ctx, lambda: ctx.decode_batch(x, max_symbols=D))
-    out.update(frames=n, slot_samples=int(x.shape[1]), dispatch=ctx.last_dispatch())
+    disp = ctx.last_dispatch()
+    span = int(x.shape[1])
+    d_all, _, _ = ctx.sc_correlate(x)
+    L, W = ctx.S, ctx.params.sync_window_reps * ctx.S
+    found = int((d_all >= 0).sum())
+    out["required_bytes_per_frame"] = (bench_cfg3.required_sync_bytes(torch, d_all, span, W, L) + found * ((5 + D) * 1024 * 8 + bench_large_n.CFG4_NBYTES)) / n
+    out["capture_throughput_of_hbm_peak"] = n * (span * 8 + bench_large_n.CFG4_NBYTES) / (out["ms"] / 1e3) / 8e12
+    out["roofline_frac"] = n * out["required_bytes_per_frame"] / (out["ms"] / 1e3) / 8e12   # on the bytes the decision requires
+    out.update(frames=n, slot_samples=span, dispatch=disp)
 elif which == "cfg5":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
     ctx = api.Context(n_fft=4096, modulation=api.QAM256, guard_bands=True)
@@ -68,7 +87,8 @@ elif which == "cfg5":
     ob = torch.empty((1, pay.numel()), dtype=torch.uint8, device=ctx.device)
     out["tx_ms"] = timed(ctx, lambda: ctx.tx_symbols(pay, out=xf))
     out["rx_ms"] = timed(ctx, lambda: ctx.rx_demod(xf.view(1, -1), syms_per_frame=n, out=ob))
-    out.update(symbols=n)
+    by = n * (ctx.S * 8 + ctx.bytes_per_symbol)
+    out.update(symbols=n, tx_roofline_frac=by / (out["tx_ms"] / 1e3) / 8e12, rx_roofline_frac=by / (out["rx_ms"] / 1e3) / 8e12)
 else:
     raise SystemExit(f"unknown configuration {which}")
 print(json.dumps(out))
