@@ -7,7 +7,8 @@ A "step" = one pass of the hot path over one batch of synthetic, HBM-resident in
 One process per GPU; frames are independent, so ranks hold disjoint frame ranges (index split, weak scaling)
 and the data path has no collective.  torch.distributed (RCCL) is only the barrier / max-time reduction.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+Prints ONE compact JSON line (< 4 KB) on rank 0 -- the headline with its `roofline` and `cpu_baseline` objects plus ms / fraction
+of the other BASELINE configurations (`configs`) -- and writes the full record of every block to --detail (bench_detail.json).
 """
 import argparse
 import json
@@ -38,6 +39,8 @@ def parse():
     ap.add_argument("--cfg4-frames", type=int, default=10_000_000, help="config 4: frames counted (BASELINE: 10M-frame stream)")
     ap.add_argument("--cfg5-symbols", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=2.5, help="wall time of each CPU-baseline leg")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (every block of every configuration); stdout carries the compact line only")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only: no GPU work, value null (CPU tests)")
     return ap.parse_args()
@@ -215,8 +218,81 @@ def dry_run(a):
                 blk["stream_frames_all_ranks"] = int(tot)
             res[name] = blk
     if grp.rank == 0:
-        print(json.dumps(res))
+        Detail(a.detail, 0).write(res)
+        print(json.dumps(compact_line(res)))
     grp.close()
+
+
+def _r(v, n=4):
+    return round(v, n) if isinstance(v, float) else v
+
+
+def _chain(blk, ms_key="ms"):
+    """ms + fractions of one chain block (a `full_chain_*` object of tools/bench_cfg3.py / tools/bench_large_n.py)."""
+    if not isinstance(blk, dict) or ms_key not in blk:
+        return None
+    return {"ms": _r(blk[ms_key]), "frac": _r((blk.get("capture_throughput") or {}).get("of_hbm_peak")),
+            "frac_required": _r((blk.get("roofline") or {}).get("frac"))}
+
+
+def compact_line(res):
+    """The ONE stdout line: the headline with `roofline` and `cpu_baseline`, plus ms + fraction of every other BASELINE
+    configuration.  Everything else (per-block rooflines, CPU legs, host-buffer and per-length blocks) lives in the detail
+    file.  Kept under 4 KB: BENCH_r04.json's `parsed` was null because this line had grown to 23 KB."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "ber_vs_tx_payload", "frames_with_errors", "dry_run", "ranks_seen", "world_size_seen",
+            "backend", "weak_scaling_efficiency_in_run", "speedup_vs_cpu", "detail")
+    line = {k: _r(res[k], 6) for k in keep if k in res}
+    if "roofline" in res:
+        rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "algorithmic_bytes_per_launch", "traffic",
+              "traffic_source", "frac_moved", "frac_of_box_ceiling", "out_buffer_population")
+        line["roofline"] = {k: _r(res["roofline"][k], 6) for k in rk if k in res["roofline"]}
+    if "cpu_baseline" in res:
+        ck = ("value", "unit", "cores", "kind", "sample", "gpu_bytes_equal_cpu_bytes")
+        line["cpu_baseline"] = {k: _r(res["cpu_baseline"][k], 3) for k in ck if k in res["cpu_baseline"]}
+    cfgs = {}
+    c3, c4, c5 = res.get("cfg3") or {}, res.get("cfg4") or {}, res.get("cfg5") or {}
+    for name, blk in (("cfg3", _chain(c3.get("full_chain_all_lags"))),
+                      ("cfg3_late", _chain((c3.get("late_packets") or {}).get("full_chain_all_lags_late_packets"))),
+                      ("cfg4", _chain(c4.get("full_chain_all_lags"), "ms_per_pass")),
+                      ("cfg4_late", _chain((c4.get("late_packets") or {}).get("full_chain_all_lags_late_packets"), "ms_per_pass"))):
+        if blk:
+            cfgs[name] = blk
+    for name, key, ms in (("cfg5_tx", "roofline_tx", "tx_ms"), ("cfg5_rx", "roofline_rx", "rx_ms")):
+        if key in c5:
+            cfgs[name] = {"ms": _r(c5.get(ms)), "frac": _r(c5[key].get("frac"))}
+    for name, blk in (("cfg3", c3), ("cfg4", c4), ("cfg5", c5)):
+        if "error" in blk:
+            cfgs[name + "_error"] = str(blk["error"])[:160]
+        elif blk.get("dry_run"):
+            cfgs[name] = {"dry_run": True, "ms": _r(blk.get("ms")), "n_gpus": blk.get("n_gpus")}
+            if "stream_frames_all_ranks" in blk:
+                cfgs[name]["stream_frames_all_ranks"] = blk["stream_frames_all_ranks"]
+    if cfgs:
+        line["configs"] = cfgs
+    if isinstance(res.get("shapes"), list):
+        line["shapes_min_frac"] = {k: min((s[k] for s in res["shapes"] if isinstance(s.get(k), float)), default=None)
+                                   for k in ("tx_frac", "rx_frac", "encode_frac")}
+    return line
+
+
+class Detail:
+    """The full record (every block, every leg) goes to a file, rewritten after each block so that a late crash loses nothing."""
+
+    def __init__(self, path, rank):
+        self.path = path if rank == 0 else None
+
+    def write(self, res):
+        if not self.path:
+            return
+        try:
+            tmp = self.path + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump(res, f, indent=1)
+            os.replace(tmp, self.path)
+        except OSError as e:  # a read-only checkout must not cost the headline
+            print(f"bench.py: could not write {self.path}: {e}", file=sys.stderr)
+            self.path = None
 
 
 def main():
@@ -306,11 +382,11 @@ def main():
     # HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_traffic.json, newest round), scaled to F: collected in
     # separate --pmc runs of tools/pmc_traffic.py (counters cannot ride along with a timed run), NOT measured in this run
     traffic = traffic_source = None
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")))["k_demod64"]
             traffic = F * (pm["read_bytes_per_frame"] + pm["write_bytes_per_frame"])
-            traffic_source = f"profiles/{rnd}_pmc_traffic.json (FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.py on the same kernel and shape; not measured in this run)"
+            traffic_source = f"profiles/{rnd}_pmc_traffic.json ({pm.get('counters', 'FETCH_SIZE / WRITE_SIZE')}; separate --pmc passes of tools/pmc_traffic.py on the same kernel and shape, not measured in this run)"
             break
         except Exception:
             pass
@@ -341,6 +417,8 @@ def main():
     roof = {"bound": "hbm", "kernel": "ofdm::k_demod64<6, true, false, 16> (BPS, GUARD, HK, groups per store burst)" if headline_dispatch == "k_demod64<burst16>" else "ofdm::" + headline_dispatch, "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes, "dispatch": headline_dispatch, **box}
+    if traffic:  # the same launch priced on the bytes the counters saw move (the cyclic prefix of a symbol is never fetched)
+        roof["frac_moved"] = traffic / kern_s / 1e9 / HBM_PEAK_GBS
 
     res = {
         "metric": "complex IQ Msamples/s through RX demod", "value": value, "unit": "Msamples/s", "n_gpus": n_gpus,
@@ -364,6 +442,14 @@ def main():
         res["cpu_baseline"] = cpu_baseline_cfg2(xh, syms, out[:ncpu].cpu().numpy(), a.cpu_seconds)
         res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"] if res["cpu_baseline"]["value"] > 0 else None
         del xh
+
+    # The headline is complete here: it goes to stderr and to the detail file NOW, so that nothing the later blocks do can lose it
+    # (the same object, with the other configurations' summaries added, is the one stdout line at the end).
+    detail = Detail(a.detail, rank)
+    res["detail"] = os.path.relpath(a.detail, ROOT) if os.path.abspath(a.detail).startswith(ROOT) else a.detail
+    if rank == 0:
+        print("bench.py headline: " + json.dumps(compact_line(res)), file=sys.stderr, flush=True)
+        detail.write(res)
 
     # BASELINE configs 3, 4, 5 at their stated sizes on this GPU (rank 0 of a single-GPU run): each block carries its own
     # roofline, bounded-sample CPU baseline and GPU-vs-CPU equality.  The headline line above must survive their failure.
@@ -389,6 +475,7 @@ def main():
                 blk = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
                 ok = 0.0
             res[name] = blk
+            detail.write(res)
             torch.cuda.empty_cache()
             if n_gpus > 1:
                 (oks,) = grp.reduce_sum(ok)
@@ -402,6 +489,7 @@ def main():
             res.update(__import__("tools.bench_host", fromlist=["run"]).run(api, torch, local))
         except Exception as e:
             res["h2d_inclusive"] = {"error": repr(e)}
+        detail.write(res)
         torch.cuda.empty_cache()
     if rank == 0 and n_gpus == 1 and not a.no_cfg3 and not a.no_shapes:
         # every transform length the library accepts: symbol-stream TX / RX and frame-level encode against their one-pass
@@ -417,7 +505,12 @@ def main():
         torch.cuda.empty_cache()
 
     if rank == 0:
-        print(json.dumps(res))
+        detail.write(res)
+        line = compact_line(res)
+        for drop in ("shapes_min_frac", "configs"):  # never reached with today's blocks; the line must parse whatever they grow into
+            if len(json.dumps(line)) >= 4096:
+                line.pop(drop, None)
+        print(json.dumps(line), flush=True)
     grp.close()
 
 
