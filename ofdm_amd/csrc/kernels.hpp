@@ -16,6 +16,8 @@ constexpr bool kProfile = OFDM_PROFILE_BUILD != 0;
 // library reads no environment variable; a host that wants one maps it onto these keys itself (tools/tune_env.py).
 struct Tuning {
     int one_pass_rx = 0;           // N = 64 decode: timing + receive body in ONE kernel / HBM pass (k_sc_cf<..., BPS>) where it fits
+    int no_sc80 = 0;               // L = 80, W = 240: the round-4 f32 filter pair (k_sc_cf<128,first> + k_sc_cf<256,list>) instead of the exact streaming detector k_sc80 (A/B)
+    int sc80_depth = 2;            // k_sc80: steps between the last read of a ring piece and its refill (1: 9 - 10 KiB in flight per wavefront, 2: 7)
     int no_sc_stream = 0;          // L = 160 .. 1280: k_scb_chunks + k_scb_fine / k_sc_tile instead of the streaming detector
     int no_sc_big = 0;             // long-period Schmidl-Cox through k_sc_tile instead of k_scb_chunks + k_scb_fine
     int no_fast64 = 0, no_demod4096 = 0, no_mid_kernels = 0, no_rxframe1024 = 0, no_txframe64 = 0; // take the generic k_sym
@@ -173,7 +175,12 @@ struct ScParams {
     const int32_t *slow_count = nullptr;
     ScStats *stats = nullptr;            // optional: where the search leaves the addresses of its list counters
 };
+struct ScExact { double pr, pi, num, den; }; // exact sums at the chosen lag; k_sc_post turns them into CFO and metric
 size_t sc_lds_bytes(const ScParams &p);
+// L = 80, W = 240 (N = 64): every lag on f64 prefix differences, one streaming pass that stops when the peak window has closed
+// (kernels_sc80.hip).  Leaves d_hat and the exact sums of the chosen lag (k_sc_post's input); frames it does not trust go to slow_list.
+bool sc80_ok(const ScParams &p);
+hipError_t launch_sc80(const ScParams &p, ScExact *exact, int32_t *slow_list, int32_t *slow_count, int num_cu, hipStream_t st);
 hipError_t run_sc(const ScParams &p, hipStream_t st);
 // fast path for one-tile frames with a short period (f32 filter + exact f64 decisions; kernels_sync.hip)
 bool sc_fast_ok(const ScParams &p);

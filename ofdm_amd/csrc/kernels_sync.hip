@@ -383,7 +383,6 @@ __device__ __forceinline__ float wave_max_nonneg(float x) {
     x = fmaxf(x, dpp_s<0x143, 0xC>(x));
     return readlane_f(x, 63);
 }
-struct ScExact { double pr, pi, num, den; }; // exact sums at the chosen lag; k_sc_post turns them into CFO and metric
 
 // Exact decision among <= 4 candidate lags of one frame (one wavefront; samples in LDS): f64 sums over the window,
 // first maximum wins.  All of a candidate's LDS reads are issued together and the four sums are reduced with DPP
@@ -1047,7 +1046,10 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     const long long gcap = tu.grid_cap > 0 ? tu.grid_cap : (1LL << 40);
     if (grid > gcap) grid = gcap;
     if (grid > p.n_frames) grid = p.n_frames;
-    if (rx) {
+    if (!rx && !tu.no_sc80 && sc80_ok(p)) {
+        // N = 64 (L = 80, W = 240): every lag exactly, one streaming pass that stops when the peak window has closed (kernels_sc80.hip)
+        if ((e = launch_sc80(p, exact, slow_list, slow_count, num_cu, st)) != hipSuccess) return e;
+    } else if (rx) {
         if (per_cu > 6) { per_cu = 6; grid = (long long)num_cu * per_cu; if (grid > gcap) grid = gcap; if (grid > p.n_frames) grid = p.n_frames; } // 3 waves per SIMD
         trace_add(p.trace, "k_sc_cf<rx>");
         switch (rx->bps) {

@@ -352,6 +352,8 @@ namespace {
 struct TuneKey { const char *name; int Tuning::*field; bool profile_only; };
 const TuneKey kTuneKeys[] = {
     {"one_pass_rx", &Tuning::one_pass_rx, false},
+    {"no_sc80", &Tuning::no_sc80, false},
+    {"sc80_depth", &Tuning::sc80_depth, false},
     {"no_sc_stream", &Tuning::no_sc_stream, false},
     {"no_sc_big", &Tuning::no_sc_big, false},
     {"no_fast64", &Tuning::no_fast64, false},

@@ -87,7 +87,7 @@ def test_decode_long_two_million_samples(api, orc):
         assert d == wd, (what, d, wd)
         if wd >= 0:
             assert abs(fd - wfd) <= 1e-9 and abs(m - wm) <= 1e-6, what
-            assert "k_sc_cf" in ctx.last_dispatch(), ctx.last_dispatch()     # the one-tile kernel serves the slices (no fallback)
+            assert "k_sc80" in ctx.last_dispatch(), ctx.last_dispatch()     # the one-tile detector serves the slices (no fallback)
         for world in (1, 2, 4, 7):
             try:
                 got = api.decode_long(x, True, api.QAM64, world=world, max_symbols=D)

@@ -367,7 +367,13 @@ def make_capture(orc, rng, mod, guard, payload, span, delay, fd, snr_db=30.0, n_
     return through_channel(orc, rng, tx, span, delay, fd, snr_db), tx
 
 
-def test_sc_correlate_batch(api, orc):
+# N = 64 searches with W = 3 L go through k_sc80 (every lag on f64 prefix differences, kernels_sc80.hip); the round-4 f32 filter pair
+# (k_sc_cf) stays in the library for other windows, for the one-pass receive kernel and as the A/B: both are held to the oracle
+SC_DETECTORS = [pytest.param({}, id="k_sc80"), pytest.param({"no_sc80": 1}, id="k_sc_cf")]
+
+
+@pytest.mark.parametrize("sc_tuning", SC_DETECTORS)
+def test_sc_correlate_batch(api, orc, sc_tuning):
     rng = np.random.default_rng(5)
     nfr, span = 48, 2176
     caps, delays, fds = [], [], []
@@ -380,8 +386,9 @@ def test_sc_correlate_batch(api, orc):
     caps = np.stack(caps)
     caps[7] = 0  # nothing to find
     caps[8] = fc32(0.05 * (rng.standard_normal(span) + 1j * rng.standard_normal(span)))  # noise only
-    ctx = api.Context(modulation=api.QAM64, guard_bands=True)
+    ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning=sc_tuning)
     d_hat, f_delta, metric = ctx.sc_correlate(dev(ctx, caps))
+    assert ("k_sc80" in ctx.last_dispatch()) == (not sc_tuning) and ("k_sc_cf" in ctx.last_dispatch()) == bool(sc_tuning), ctx.last_dispatch()
     d_hat, f_delta, metric = host(d_hat), host(f_delta), host(metric)
     for f in range(nfr):
         wd, wp, wm, wfd = orc.sc_sync(wide(caps[f]), 80, 3, 0, 0.5)
@@ -418,7 +425,7 @@ def test_sc_correlate_two_launch_search_equals_the_whole_search(api, orc, reps):
     want = [orc.sc_sync(wide(c), 80, reps, 0, 0.5) for c in caps[: len(delays) + 2]]
     ref = None
     for first in (0,) + firsts:
-        ctx = api.Context(modulation=api.QAM64, guard_bands=True, sync_window_reps=reps, tuning={"sc_first_lags": first, "grid_cap": 5})
+        ctx = api.Context(modulation=api.QAM64, guard_bands=True, sync_window_reps=reps, tuning={"sc_first_lags": first, "grid_cap": 5, "no_sc80": 1})
         d_hat, f_delta, metric = (host(t) for t in ctx.sc_correlate(dev(ctx, caps)))
         disp = ctx.last_dispatch()
         assert ("k_sc_cf<128,first>+k_sc_cf<256,list>" in disp) == (first > 0), disp
@@ -434,13 +441,21 @@ def test_sc_correlate_two_launch_search_equals_the_whole_search(api, orc, reps):
     # the decode chain takes the same path
     res = []
     for first in (0, 384, 576):
-        ctx = api.Context(modulation=api.QAM64, guard_bands=True, sync_window_reps=reps, tuning={"sc_first_lags": first})
+        ctx = api.Context(modulation=api.QAM64, guard_bands=True, sync_window_reps=reps, tuning={"sc_first_lags": first, "no_sc80": 1})
         r = ctx.decode_batch(dev(ctx, caps), max_symbols=8)
         assert ("k_sc_cf<128,first>+k_sc_cf<256,list>" in ctx.last_dispatch()) == (first > 0), ctx.last_dispatch()
         res.append({k: host(v) for k, v in r.items()})
+    # ... and the exact streaming detector (the default for W = 3 L), on a capped grid: the same decisions, sums equal to rounding
+    ctx = api.Context(modulation=api.QAM64, guard_bands=True, sync_window_reps=reps, tuning={"grid_cap": 3})
+    d80, f80, m80 = (host(t) for t in ctx.sc_correlate(dev(ctx, caps)))
+    assert ("k_sc80" in ctx.last_dispatch()) == (reps == 3), ctx.last_dispatch()
+    assert (d80 == ref[0]).all() and np.abs(f80 - ref[1]).max() <= 1e-12 and np.abs(m80 - ref[2]).max() <= 1e-6
+    r = ctx.decode_batch(dev(ctx, caps), max_symbols=8)
+    res.append({k: host(v) for k, v in r.items()})
     for other in res[1:]:
-        for k in ("status", "offset", "len", "f_delta"):
+        for k in ("status", "offset", "len"):
             assert (res[0][k] == other[k]).all(), k
+        assert np.abs(res[0]["f_delta"] - other["f_delta"]).max() <= 1e-12
         for f in range(caps.shape[0]):   # rows are defined up to the frame's length only
             assert (res[0]["bytes"][f, : res[0]["len"][f]] == other["bytes"][f, : other["len"][f]]).all(), f
     assert int((res[0]["status"][:20] == 0).sum()) >= 18
@@ -456,7 +471,7 @@ def test_sc_first_lags_at_the_edge_of_the_first_tile(api, orc):
     caps = np.stack([through_channel(orc, rng, tx, span, d, 0.01, 30.0) for d in (5, 380, 400, 330, 270, 410)])
     want = [orc.sc_sync(wide(c), 80, 3, 0, 0.5) for c in caps]
     for first, kernel in ((948, "k_sc_cf<128,first>"), (949, "k_sc_cf<256>"), (955, "k_sc_cf<256>"), (1280, "k_sc_cf<256>")):
-        ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning={"sc_first_lags": first})
+        ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning={"sc_first_lags": first, "no_sc80": 1})
         d, fd, m = ctx.sc_correlate(dev(ctx, caps))
         assert kernel in ctx.last_dispatch(), (first, ctx.last_dispatch())
         for f, (wd, _, wm, wfd) in enumerate(want):
@@ -467,7 +482,51 @@ def test_sc_first_lags_at_the_edge_of_the_first_tile(api, orc):
             ctx.set_tuning(key, bad)
 
 
-def test_sc_correlate_untrusted_f32_filter(api, orc):
+def test_sc80_streaming_detector_corner_cases(api, orc):
+    """k_sc80 (kernels_sc80.hip) on what its design has to get right: batches that do not fill the last wavefront's four rows, a
+    capped grid walking many groups, bounded searches and captures barely longer than one window (the stream is clamped at the
+    last sample a lag reads), thresholds that are not a power of two (the crossing filter's fused compare), all-zero lead-ins
+    (exact prefix differences: no slow list), and captures whose dynamic range defeats prefix differences -- an exact-zero gap
+    behind a burst, a packet 75 dB below a burst -- which must come back from the slow list with the oracle's answer."""
+    rng = np.random.default_rng(80)
+    span = 2176
+    tx = orc.encode(bytes(rng.integers(0, 256, 560, dtype=np.uint8)), True, orc.QAM64)
+    ordinary = [through_channel(orc, rng, tx, span, int(d), float(fd), 30.0) for d, fd in
+                zip(rng.integers(1, 80, 13), (rng.random(13) * 1.9 - 0.95) * np.pi / 80)]
+    # (a) ragged batches, capped grid, bounded and short searches, other thresholds
+    for nfr in (1, 2, 3, 5, 13):
+        caps = np.stack(ordinary[:nfr])
+        for thr, n_lags, flen in ((0.5, 0, span), (0.37, 0, span), (0.81, 300, span), (0.5, 0, 400), (0.5, 0, 322), (0.5, 45, 2000)):
+            ctx = api.Context(modulation=api.QAM64, guard_bands=True, sync_threshold=thr, tuning={"grid_cap": 2})
+            d_hat, f_delta, metric = (host(t) for t in ctx.sc_correlate(dev(ctx, caps), frame_len=flen, n_lags=n_lags))
+            assert ctx.last_dispatch().startswith("k_sc80"), ctx.last_dispatch()
+            for f in range(nfr):
+                wd, _, wm, wfd = orc.sc_sync(wide(caps[f][:flen]), 80, 3, n_lags, thr)
+                assert d_hat[f] == wd, (nfr, thr, n_lags, flen, f, int(d_hat[f]), wd)
+                if wd >= 0:
+                    assert abs(f_delta[f] - wfd) <= 1e-9 and abs(metric[f] - wm) <= 1e-6, (nfr, thr, n_lags, flen, f)
+    # (b) dynamic range
+    clean = np.zeros(span, complex); clean[500:500 + 1600] = tx[:1600]            # zeros, then a noiseless frame: exact, stays on the fast path
+    lead = fc32(clean)
+    gap = clean.copy(); gap[3:40] += 30.0 * (rng.standard_normal(37) + 1j * rng.standard_normal(37))      # burst, EXACT zeros, frame
+    quiet = 1e-3 * wide(ordinary[0]); quiet[5:25] += 3.0 * (rng.standard_normal(20) + 1j * rng.standard_normal(20))     # burst, then a packet 75 dB down
+    hot = wide(ordinary[1]).copy(); hot[2:14] += 40.0 * (rng.standard_normal(12) + 1j * rng.standard_normal(12))       # burst 50 dB up: trusted
+    caps = np.stack([lead, fc32(gap), fc32(quiet), fc32(hot), ordinary[2]])
+    ctx = api.Context(modulation=api.QAM64, guard_bands=True)
+    d_hat, f_delta, metric = (host(t) for t in ctx.sc_correlate(dev(ctx, caps[:1])))
+    assert ctx.get_tuning("stat_sc_slow_frames") == 0 and d_hat[0] == orc.sc_sync(wide(lead), 80, 3, 0, 0.5)[0] >= 0
+    d_hat, f_delta, metric = (host(t) for t in ctx.sc_correlate(dev(ctx, caps)))
+    slow = ctx.get_tuning("stat_sc_slow_frames")
+    assert 2 <= slow <= 3, slow                                                   # the gap and the quiet packet (the hot one may or may not be trusted)
+    for f in range(caps.shape[0]):
+        wd, _, wm, wfd = orc.sc_sync(wide(caps[f]), 80, 3, 0, 0.5)
+        assert d_hat[f] == wd, (f, int(d_hat[f]), wd)
+        if wd >= 0:
+            assert abs(f_delta[f] - wfd) <= 1e-9 and abs(metric[f] - wm) <= 1e-6 * max(1.0, wm), f
+
+
+@pytest.mark.parametrize("sc_tuning", SC_DETECTORS)
+def test_sc_correlate_untrusted_f32_filter(api, orc, sc_tuning):
     # A strong burst ahead of the frame makes the prefix energy >> window energy, so the fast kernel's f32 filter must
     # not be trusted there: those frames are redone by the all-f64 kernel (device-side slow list).  Results still exact.
     rng = np.random.default_rng(12)
@@ -480,14 +539,15 @@ def test_sc_correlate_untrusted_f32_filter(api, orc):
             c[2:14] += fc32(40.0 * (rng.standard_normal(12) + 1j * rng.standard_normal(12)))
         caps.append(c)
     caps = np.stack(caps)
-    ctx = api.Context(modulation=api.QAM64, guard_bands=True)
+    ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning=sc_tuning)
     d_hat, f_delta, metric = (host(t) for t in ctx.sc_correlate(dev(ctx, caps)))
     for f in range(24):
         wd, _, wm, wfd = orc.sc_sync(wide(caps[f]), 80, 3, 0, 0.5)
         assert d_hat[f] == wd and abs(f_delta[f] - wfd) <= 1e-9 and abs(metric[f] - wm) <= 1e-6, f"frame {f}"
 
 
-def test_sc_correlate_coarse_fine_corner_cases(api, orc):
+@pytest.mark.parametrize("sc_tuning", SC_DETECTORS)
+def test_sc_correlate_coarse_fine_corner_cases(api, orc, sc_tuning):
     """The coarse-then-fine filter's less-travelled paths, against the f64 oracle on synthetic period-80 signals:
     false alarms (a flagged chunk whose 320-lag group holds no crossing), a metric that creeps up so that the crossing
     lies late in its group (restart at the crossing's chunk), frames that are periodic everywhere (every chunk
@@ -527,7 +587,7 @@ def test_sc_correlate_coarse_fine_corner_cases(api, orc):
             x = noise(float(rng.uniform(0.55, 0.8))) + periodic(int(rng.integers(0, 600)), span, 1.0)
         caps.append(fc32(x))
     caps = np.stack(caps)
-    ctx = api.Context(modulation=api.QAM64, guard_bands=True)
+    ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning=sc_tuning)
     for n_lags in (0, 1000):
         d_hat, f_delta, metric = (host(t) for t in ctx.sc_correlate(dev(ctx, caps), n_lags=n_lags))
         found = ties = 0
@@ -559,8 +619,9 @@ def test_sc_correlate_randomised_stress(ofdm):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sc_stress.py"), "600", "3"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.count(" 0 mismatches") == 4, r.stdout[-2000:] + r.stderr[-2000:]
+    for detector in ("k_sc80", "k_sc_cf"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "sc_stress.py"), "600", "3", detector], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.count(" 0 mismatches") == 4, detector + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_sc_correlate_long_capture_multi_tile(api, orc):
@@ -848,7 +909,7 @@ def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod,
             assert ctx1.last_dispatch().startswith("k_sc_cf<rx>+k_sc_tile<list>+k_rx_prepare<list>+k_rxframe64<list>"), ctx1.last_dispatch()
             two = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=max_sym, frame_len=flen_used).items()}
             d2 = ctx.last_dispatch()
-            assert d2.startswith("k_sc_cf<") and "<rx>" not in d2 and "+k_rx_prepare+k_rxframe64" in d2, d2
+            assert d2.startswith("k_sc80+") and "<rx>" not in d2 and "+k_rx_prepare+k_rxframe64" in d2, d2
             assert np.array_equal(one["status"], two["status"]) and np.array_equal(one["offset"], two["offset"])
             assert np.array_equal(one["len"], two["len"])
             assert np.allclose(one["f_delta"], two["f_delta"], rtol=0, atol=1e-13)

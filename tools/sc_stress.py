@@ -38,10 +38,13 @@ for f in range(n):
         buf += 0.5 * np.sqrt(p) * np.exp(1j * 2 * np.pi * float(rng.uniform(0, 0.5)) * np.arange(span))
     caps.append(fc32(buf))
 caps = np.stack(caps)
-ctx = api.Context(modulation=api.QAM64, guard_bands=True)
+# detector: k_sc80 (exact streaming detector, the default) or k_sc_cf (the f32 filter pair, tuning no_sc80)
+detector = sys.argv[3] if len(sys.argv) > 3 else "k_sc80"
+ctx = api.Context(modulation=api.QAM64, guard_bands=True, tuning={"no_sc80": 1} if detector == "k_sc_cf" else {})
 bad = 0
 for n_lags, flen in ((0, span), (256, span), (0, 2000), (700, 1800)):
     d_hat, f_delta, metric = (t.cpu().numpy() for t in ctx.sc_correlate(ctx.to_device(caps), frame_len=flen, n_lags=n_lags))
+    assert detector in ctx.last_dispatch(), ctx.last_dispatch()
     nb = nf = 0
     for f in range(n):
         wd, _, wm, wfd = orc.sc_sync(wide(caps[f][:flen]), 80, 3, n_lags, 0.5)
