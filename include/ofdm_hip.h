@@ -68,11 +68,10 @@ enum { OFDM_CFO_OFF = 0, OFDM_CFO_SIGNED = 1, OFDM_CFO_ABS = 2 }; /* ABS = refer
  * with the locking signal (xcorr_fft, src/signals/mod.rs:186-217; offset = idx_max - N = lag - 1, src/receiver.rs:20-25) and
  * frequency_correction on preamble repetitions 3 and 4 (src/receiver.rs:39, 231-240; always |.|) */
 enum { OFDM_SYNC_SCHMIDL_COX = 0, OFDM_SYNC_REFERENCE = 1 };
-/* how ofdm_rx_decode_batch runs the N = 64 chain (src/receiver.rs:9-96) when Schmidl-Cox timing is on: STAGED = timing kernel,
- * then one receive kernel per frame (two passes over the capture); ONE_PASS = timing, CFO, channel estimate, demod and the
- * length-header finish in ONE kernel from one LDS image of the frame (one pass over HBM; frames that do not fit its envelope,
- * see DESIGN.md 5.2, take the staged chain).  AUTO = the faster of the two as measured on MI355X.  Results are identical. */
-enum { OFDM_RX_AUTO = 0, OFDM_RX_STAGED = 1, OFDM_RX_ONE_PASS = 2 };
+/* ofdm_params.rx_path: rounds 2-4 offered a second N = 64 receive chain here (ONE_PASS = 2: timing and receive body in one kernel
+ * from one LDS image).  It never beat the staged chain (7.4 against 4.5 ms per 1 M config-3 frames in round 5) and was removed;
+ * the slot stays so that the struct layout does not change, and takes AUTO or STAGED (the same chain). */
+enum { OFDM_RX_AUTO = 0, OFDM_RX_STAGED = 1 };
 
 typedef struct {
     int32_t n_fft;            /* sub-carriers: 64 (reference) .. 4096, power of two */
@@ -85,7 +84,7 @@ typedef struct {
     int32_t cfo_mode;         /* OFDM_CFO_* , default SIGNED */
     float sync_threshold;     /* packet-detect threshold on M(d), default 0.5 */
     int32_t sync_mode;        /* OFDM_SYNC_*, default SCHMIDL_COX (this slot was reserved[0] == 0: same layout, same default) */
-    int32_t rx_path;          /* OFDM_RX_*, default AUTO (this slot was reserved[0] == 0: same layout, same default) */
+    int32_t rx_path;          /* OFDM_RX_AUTO or OFDM_RX_STAGED: one chain exists (see above) */
     int32_t reserved[5];      /* must be zero */
 } ofdm_params;
 
@@ -125,17 +124,16 @@ int ofdm_last_hip_error(const ofdm_ctx *ctx); /* raw hipError_t of the last fail
  * oddly strided buffers, soft outputs -- with the same results; this call is how a caller (and the parity tests) tell which
  * one ran.  Returns the full length of the string (like snprintf), buf receives at most n - 1 characters. Host call. */
 int ofdm_last_dispatch(const ofdm_ctx *ctx, char *buf, size_t n);
-/* Per-context tuning: A/B switches between kernel families and grid shapes.  The library reads NO environment variable.
- * Keys (value >= 0): "one_pass_rx" 0/1 (overrides ofdm_params.rx_path), "no_sc_stream", "no_sc_big", "no_rx1024_finish", "no_rxframe64_split" (1: one N = 64 receive kernel with both frame bodies instead of the common-body / cut-body pair), "no_fast64", "no_demod4096",
- * "no_mid_kernels", "no_rxframe1024", "no_txframe64" (1 = take the generic kernel instead of that family), "grid_cap"
- * (> 0: caps every persistent grid -- the tests use it to run many pipeline steps per workgroup on small batches),
- * "tx_waves", "txframe_keep_steps" (1: frames that fit one step of k_txframe_mid are built once; 0: always twice), "txframe_rewrite" (1: longer frames are built once, stored unnormalised and rescaled in a second sweep -- measured slower, A/B only), "sc_wg_per_cu", "sc_first_lags" (N = 64 searches: lags of the first of two launches, 0 = one launch), "sc128_one_wave" (1: one wavefront per frame in the 128-chunk k_sc_cf), "demod64_wg_per_cu", "demod64_burst" (16 / 8 / 4 / 1), "demod64_narrow_stores",
- * "scb_two_segments", "scb_big_tiles"; "debug_demod64", "debug_sc", "debug_tx" select ablation exits / section timers
- * that exist only in the profile build of the library (libofdm_hip_profile.so, -DOFDM_PROFILE_BUILD=1): the product build
- * answers OFDM_ERR_UNSUPPORTED.  Unknown key: OFDM_ERR_INVALID.  ofdm_get_tuning also answers "profile_build" and two counters of
- * the context's LAST N = 64 Schmidl-Cox search (it synchronises the stream; -1 = that search kept no such list): "stat_sc_slow_frames"
- * (frames the f32 filter handed to the all-f64 kernel) and "stat_sc_redo_frames" (frames the first launch of the two-launch search
- * left to the whole search).  Host calls. */
+/* Per-context knobs and counters.  The library reads NO environment variable.  Keys a host legitimately needs:
+ *   "grid_cap"             set/get, > 0 caps every persistent grid (0 = sized from the device); the parity tests use it to make small
+ *                          batches walk many pipeline steps per workgroup
+ *   "profile_build"        get: 1 in libofdm_hip_profile.so (-DOFDM_PROFILE_BUILD=1), 0 in the product build
+ *   "stat_sc_slow_frames"  get: frames of the context's LAST N = 64 Schmidl-Cox search that were redone by the all-f64 kernel
+ *   "stat_sc_redo_frames"  get: frames the first launch of the two-launch filter search left to the whole search
+ *                          (both synchronise the stream; -1 = that search kept no such list)
+ * Every other key is a laboratory switch between kernel variants (A/B measurements, profiling exits): listed and described in
+ * ofdm_amd/csrc/ofdm_hip_tuning.h, NOT part of the drop-in contract, free to change between releases.  Unknown key: OFDM_ERR_INVALID;
+ * a profiling key in the product build: OFDM_ERR_UNSUPPORTED.  Host calls. */
 int ofdm_set_tuning(ofdm_ctx *ctx, const char *key, int64_t value);
 int ofdm_get_tuning(const ofdm_ctx *ctx, const char *key, int64_t *value);
 
@@ -287,7 +285,8 @@ int ofdm_rx_decode_host(ofdm_ctx *ctx, const ofdm_fc32 *in_host, int64_t n_frame
 /* ofdm_rx_demod_batch on host buffers for regular streams (no offsets, no CFO, H == 1): the BASELINE metric's path. */
 int ofdm_rx_demod_host(ofdm_ctx *ctx, const ofdm_fc32 *in_host, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
                        int32_t first_symbol, int32_t syms_per_frame, uint8_t *out_host, int64_t out_stride, int64_t chunk_frames);
-/* ofdm_tx_encode_batch on host buffers (payload_len_host may be NULL; row f is read for its own length only). */
+/* ofdm_tx_encode_batch on host buffers (payload_len_host may be NULL; row f is read for its own length only).  A length above
+ * payload_bytes is clamped to payload_bytes, as the device entry point clamps it; the samples are those of ofdm_tx_encode_batch. */
 int ofdm_tx_encode_host(ofdm_ctx *ctx, const uint8_t *payload_host, int64_t n_frames, int64_t payload_stride,
                         const int32_t *payload_len_host, int32_t payload_bytes, ofdm_fc32 *out_host, int64_t out_stride,
                         int64_t chunk_frames);
@@ -306,8 +305,11 @@ int ofdm_tx_encode_host(ofdm_ctx *ctx, const uint8_t *payload_host, int64_t n_fr
 int ofdm_sc_correlate_long(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_samples, int64_t lag_lo, int64_t lag_hi,
                            int64_t slice_lags, int64_t *d_hat, double *f_delta, float *metric);
 /* decode (src/receiver.rs:9-96) of ONE long capture: the search above over [lag_lo, lag_hi) (skipped when d_hat_known >= 0: a
- * detection merged from several contexts), then the receive chain from that frame on.  Identical to ofdm_rx_decode_batch with
- * n_frames = 1 on the whole capture: status, offset (into the capture), CFO, metric, bytes.  out_dev[0 .. out_cap) is a DEVICE
+ * detection merged from several contexts), then the receive chain from that frame on.  With the whole lag range it is identical to
+ * ofdm_rx_decode_batch with n_frames = 1 on the whole capture: status, offset (into the capture), CFO, metric, bytes -- except that
+ * a capture without a detection (OFDM_FRAME_NOSYNC) reports f_delta = metric = 0 without running the chain.  With lag_lo > 0 the
+ * detection is the first crossing at or after lag_lo (lags in front of it are never looked at, although the frame's own first
+ * samples may lie there), i.e. the result of ofdm_rx_decode_batch on the capture from lag_lo on, re-based to the whole capture.  out_dev[0 .. out_cap) is a DEVICE
  * buffer (out_cap as out_stride there); out_len, status, offset, f_delta, metric are HOST pointers (the last three optional).
  * With sync_mode = OFDM_SYNC_REFERENCE the lag range must be the whole capture. */
 int ofdm_rx_decode_long(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_samples, int64_t lag_lo, int64_t lag_hi,

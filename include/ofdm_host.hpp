@@ -161,11 +161,21 @@ class Context {
 
 // One context per (thread, parameter set), created on first use and kept: the reference's free functions are called once per
 // frame (examples/lab3a.rs:24,34, jetson_rx.rs:86), and ofdm_create -- table uploads, stream and workspace set-up -- must not be
-// paid on every call.
+// paid on every call.  The cache is thread_local: its contexts are destroyed (ofdm_destroy: HIP calls) when the THREAD exits.  A host
+// that ends threads after the HIP runtime has been torn down (static destruction order, exit() from another thread) must call
+// clear_cached_contexts() on that thread first.
+namespace detail {
+using ContextKey = std::tuple<bool, int, int, int, int, int, int>;
+inline std::map<ContextKey, std::unique_ptr<Context>> &context_cache() {
+    thread_local std::map<ContextKey, std::unique_ptr<Context>> cache;
+    return cache;
+}
+} // namespace detail
+inline void clear_cached_contexts() { detail::context_cache().clear(); } // this thread's contexts, now
 inline Context &cached_context(bool guard_bands, ModulationScheme m, int n_fft = 64, int ecc = OFDM_ECC_NONE,
                                int cfo_mode = OFDM_CFO_SIGNED, int device = 0) {
-    using Key = std::tuple<bool, int, int, int, int, int, int>;
-    thread_local std::map<Key, std::unique_ptr<Context>> cache;
+    using Key = detail::ContextKey;
+    auto &cache = detail::context_cache();
     const Key k{guard_bands, (int)m, n_fft, ecc, cfo_mode, device, (int)default_pilot_choice()};
     auto it = cache.find(k);
     if (it == cache.end()) it = cache.emplace(k, std::make_unique<Context>(guard_bands, m, n_fft, ecc, cfo_mode, device)).first;
@@ -236,6 +246,11 @@ class ShardedContext {
         const size_t R = ctx_.size();
         std::vector<int> rc(R, OFDM_OK);
         std::vector<std::thread> th;
+        th.reserve(R); // no reallocation while threads run
+        struct Joiner { // whatever happens below (std::thread's constructor can throw), started shards are joined before the stack unwinds:
+            std::vector<std::thread> &t; // a joinable std::thread destroyed means std::terminate with GPU work in flight
+            ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); }
+        } joiner{th};
         for (size_t i = 0; i < R; ++i) {
             const auto [lo, hi] = shard_range(n_frames, (int64_t)i, (int64_t)R);
             if (hi > lo) th.emplace_back([&, i, lo = lo, hi = hi] { rc[i] = shard(i, lo, hi); }); // every entry point selects its context's device itself

@@ -22,7 +22,7 @@ ECC_NONE, ECC_HAMMING74 = 0, 1
 CFO_OFF, CFO_SIGNED, CFO_ABS = 0, 1, 2
 FRAME_OK, FRAME_SHORT, FRAME_NOSYNC, FRAME_BADTIMING, FRAME_HEADER = 0, -1, -2, -3, -4
 SYNC_SCHMIDL_COX, SYNC_REFERENCE = 0, 1
-RX_AUTO, RX_STAGED, RX_ONE_PASS = 0, 1, 2
+RX_AUTO, RX_STAGED = 0, 1
 DEFAULT_TUNING: dict = {}  # merged under every Context's `tuning=` (tools/tune_env.py fills it; empty in tests, bench and smoke)
 
 
@@ -82,6 +82,19 @@ def decipher_transmission_bytes(code: bytes) -> Optional[bytes]:
         return None
     _check(lib, rc, "ofdm_rs255_decode")
     return bytes(out)
+
+
+def sig_to_bytes(sig) -> bytes:
+    """utils::sig_to_bytes (src/utils.rs:228-236): Complex64 samples -> native-endian f32 (re, im) pairs, the `fc32` format of
+    UHD's `--type float` tools (data/transmit.sh:1) and the layout every kernel of this library reads and writes."""
+    return np.ascontiguousarray(np.asarray(sig), dtype=np.complex64).tobytes()
+
+
+def bytes_to_sig(buf: bytes) -> np.ndarray:
+    """utils::bytes_to_sig (src/utils.rs:238-254): fc32 bytes -> Complex64 samples (a trailing partial sample is dropped, as
+    `as_chunks` drops it)."""
+    n = len(buf) // 8
+    return np.frombuffer(buf, dtype=np.complex64, count=n).astype(np.complex128)
 
 
 def locking_signal(length: int = 80) -> np.ndarray:

@@ -20,7 +20,7 @@ LIB = os.path.join(HERE, "libofdm_hip.so")
 LIB_PROFILE = os.path.join(HERE, "libofdm_hip_profile.so")
 OBJ_PROFILE = os.path.join(CSRC, "_obj_profile")
 SOURCES = ["kernels_sym.hip", "kernels_fast.hip", "kernels_rx1024.hip", "kernels_mid.hip", "kernels_sync.hip", "kernels_sc80.hip", "kernels_scstream.hip", "kernels_scbig.hip", "kernels_bytes.hip", "ofdm_abi.hip", "ofdm_host_path.hip", "outer_code.hip"]
-HEADERS = ["device_common.hpp", "kernels.hpp", "ofdm_ctx.hpp", os.path.join("..", "..", "include", "ofdm_hip.h")]
+HEADERS = ["device_common.hpp", "kernels.hpp", "ofdm_ctx.hpp", "ofdm_hip_tuning.h", os.path.join("..", "..", "include", "ofdm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # per-file additions.  kernels_sync: the SLP vectoriser pairs f32 ops into v_pk_* and pays for it in v_mov (measured:
 # 332 -> 246 VALU in the filter's phase 1, 16 fewer VGPRs)

@@ -15,7 +15,6 @@ constexpr bool kProfile = OFDM_PROFILE_BUILD != 0;
 // Per-context tuning (ofdm_set_tuning): A/B switches between kernel families, grid shapes and the tests' grid cap.  The
 // library reads no environment variable; a host that wants one maps it onto these keys itself (tools/tune_env.py).
 struct Tuning {
-    int one_pass_rx = 0;           // N = 64 decode: timing + receive body in ONE kernel / HBM pass (k_sc_cf<..., BPS>) where it fits
     int no_sc80 = 0;               // L = 80, W = 240: the round-4 f32 filter pair (k_sc_cf<128,first> + k_sc_cf<256,list>) instead of the exact streaming detector k_sc80 (A/B)
     int sc80_depth = 2;            // k_sc80: steps between the last read of a ring piece and its refill (1: 9 - 10 KiB in flight per wavefront, 2: 7)
     int no_sc_stream = 0;          // L = 160 .. 1280: k_scb_chunks + k_scb_fine / k_sc_tile instead of the streaming detector
@@ -57,12 +56,13 @@ struct Trace {
 };
 inline void trace_add(Trace *t, const char *name) { if (t) t->add(name); }
 
-// Device-side counters of the last Schmidl-Cox search on a context (ofdm_get_tuning "stat_sc_slow_frames" / "stat_sc_redo_frames"):
-// how many frames the f32 filter handed to the all-f64 kernel, and how many the first launch of the two-launch search left to
-// the whole search.  Pointers into the search's workspace; nullptr when the last search kept no such list.
+// Counters of the last Schmidl-Cox search on a context (ofdm_get_tuning "stat_sc_slow_frames" / "stat_sc_redo_frames"): how many
+// frames went to the all-f64 kernel, and how many the first launch of the two-launch search left to the whole search.  `dev` is a
+// small device buffer OWNED BY THE CONTEXT ([0] slow, [1] redo): the search copies its counters there on its stream, so that the
+// figures survive the search's workspace being regrown or reused by another entry point.
 struct ScStats {
-    const int32_t *slow_count = nullptr;
-    const int32_t *redo_count = nullptr;
+    int32_t *dev = nullptr;
+    bool has_slow = false, has_redo = false;
 };
 
 struct SymParams {
@@ -185,21 +185,7 @@ hipError_t run_sc(const ScParams &p, hipStream_t st);
 // fast path for one-tile frames with a short period (f32 filter + exact f64 decisions; kernels_sync.hip)
 bool sc_fast_ok(const ScParams &p);
 size_t sc_fast_workspace_bytes(long long n_frames, int W);
-// fused timing + receive body for N = 64 frames that fit one tile (k_sc_cf<..., BPS != 0>): one pass over HBM for the whole
-// decode.  Frames the f32 filter cannot settle stay on the slow list for the list-mode kernels below.
-struct ScRxFused {
-    int bps = 0, guard = 0, backoff = 0, cfo_mode = 0, max_symbols = 0, ecc = 0;
-    const float2 *tw = nullptr, *inv_training = nullptr;
-    const double *atan_tab = nullptr;
-    unsigned char *out = nullptr;
-    long long out_stride = 0;
-    int32_t *out_len = nullptr, *status = nullptr, *offset = nullptr;
-    double *f_delta = nullptr;
-    float *metric = nullptr;
-};
-bool sc_rx_fused_ok(const ScParams &p, const ScRxFused &rx);
-hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st, const ScRxFused *rx = nullptr,
-                       const int32_t **slow_list = nullptr, const int32_t **slow_count = nullptr);
+hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st);
 // periods L = 160 .. 1280 (N = 128 .. 1024): one streaming pass per frame that stops once the decision is determined
 // (kernels_scstream.hip)
 bool sc_stream_ok(const ScParams &p);
@@ -256,6 +242,8 @@ hipError_t run_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_de
                           int backoff, int cfo_mode, int max_symbols, int bytes_per_symbol, int32_t *status,
                           int32_t *offset, int32_t *nsym, hipStream_t st, const int32_t *frame_list = nullptr,
                           const int32_t *frame_count = nullptr);
+// one capture's timing written where the search would have left it (ofdm_abi_rx_decode_known)
+hipError_t run_set_sync(int32_t *d_hat, double *f_delta, float *metric, int32_t d, double fd, float m, hipStream_t st);
 // RX finish: header parse + truncate [+ Hamming decode] (receiver.rs:85-95)
 hipError_t run_rx_finish(const uint8_t *raw, long long raw_stride, long long n_frames, const int32_t *status,
                          const int32_t *nsym, int bytes_per_symbol, int ecc, uint8_t *out, long long out_stride,

@@ -267,6 +267,14 @@ hipError_t run_rx_prepare(long long n_frames, const int32_t *d_hat, double *f_de
     return hipGetLastError();
 }
 
+__global__ void k_set_sync(int32_t *d_hat, double *f_delta, float *metric, int32_t d, double fd, float m) {
+    if (threadIdx.x == 0) { d_hat[0] = d; f_delta[0] = fd; if (metric) metric[0] = m; }
+}
+hipError_t run_set_sync(int32_t *d_hat, double *f_delta, float *metric, int32_t d, double fd, float m, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_sync, dim3(1), dim3(64), 0, st, d_hat, f_delta, metric, d, fd, m);
+    return hipGetLastError();
+}
+
 // header parse + truncate (src/receiver.rs:85-95) [+ Hamming(7,4) decode]: one wavefront per frame
 __global__ __launch_bounds__(256) void k_rx_finish(const uint8_t *raw, long long raw_stride, long long n_frames,
                                                    const int32_t *status, const int32_t *nsym, int bytes_per_symbol,

@@ -302,20 +302,6 @@ __device__ __forceinline__ void wave_sum4(double &a, double &b, double &c, doubl
     a = readlane_d(k, 0); b = readlane_d(k, 1); c = readlane_d(k, 2); d = readlane_d(k, 3);
 }
 
-// Receive body fused behind the timing search (k_sc_cf<..., BPS != 0>): what k_sc_post + k_rx_prepare + k_rxframe64 +
-// k_rx_finish do in four more launches and a second HBM pass, done from the frame's LDS image.
-struct ScRxParams {
-    long long frame_len = 0;
-    int backoff = 0, cfo_mode = 0, max_symbols = 0, ecc = 0;
-    const float2 *tw = nullptr, *inv_training = nullptr;
-    const double *atan_tab = nullptr; // 32 x (cos, sin)(k pi / 16), f64
-    unsigned char *out = nullptr;     // final payload bytes, 4-byte aligned rows
-    long long out_stride = 0;
-    int32_t *out_len = nullptr, *status = nullptr, *offset = nullptr;
-    double *f_delta = nullptr;
-    float *metric = nullptr;          // optional
-};
-
 struct ScFastParams {
     const float2 *in;
     long long n_frames, frame_stride;
@@ -334,7 +320,6 @@ struct ScFastParams {
     int32_t *redo_list, *redo_count;
     const int32_t *frame_list;    // optional: only these frames (count on the device)
     const int32_t *frame_count;
-    ScRxParams rx;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -361,18 +346,6 @@ struct ScFastParams {
 // 1.3 / 6.0 thousand s_memtime ticks; the fine wavefront is the critical path, which is why its LDS reads are issued
 // up front (one round trip per stage) and its reductions never touch LDS.
 //
-// BPS != 0: the whole decode (src/receiver.rs:9-96) in this one pass over HBM -- the frame is already in LDS, so after the
-// timing decision the workgroup runs the receive body from that image:
-//   fine wavefront   CFO = arg P / L (f64: table + short series instead of libm atan2), trimmed start, length check, live
-//                    symbols (receiver.rs:21-39); estimate_channel on the 5 training blocks (receiver.rs:212-229) -> 1/H
-//                    to LDS; the FFT transposes run IN PLACE in each symbol's own 80-sample LDS slot;
-//   both wavefronts  one group of 8 data symbols each per step: CFO derotation (receiver.rs:44-50), CP strip + FFT64
-//                    (receiver.rs:99-104), equalise (:68-70), pilot phase (:106-145), hard demap + LSB-first packing
-//                    (:147-190) into the frame's packed image in LDS (it overlays the dead chunk arrays);
-//   all threads      16-byte length header, truncate (receiver.rs:85-95) [, Hamming(7,4) decode], payload bytes to their
-//                    final place with dword stores.
-// HBM traffic of the chain: the capture once (8 B/sample) + the decoded bytes.  Frames the f32 filter cannot settle go
-// to the slow list and are redone by k_sc_tile + the list-mode receive kernels.
 // maximum of non-negative values over the wavefront, DPP only (no LDS round trips): a max-scan leaves it in lane 63
 __device__ __forceinline__ float wave_max_nonneg(float x) {
     x = fmaxf(x, dpp_s<0x111, 0xF>(x));
@@ -437,39 +410,14 @@ __global__ __launch_bounds__(256) void k_sc_post(const int32_t *d_hat, const ScE
     if (metric) metric[f] = found ? (float)(e.num / e.den) : 0.f;
 }
 
-extern "C" __device__ float __ocml_atan2pi_f32(float, float);
-// atan2(y, x) in f64 for the fused receive body: octant from an f32 estimate, exact f64 rotation by a tabulated angle
-// (32 entries of (cos, sin)(k pi / 16), wave-uniform index: scalar loads), then atan of the small residual by its series (|r| <= tan(pi/32 + 1e-6):
-// the r^17 term is below 1e-18).  ~1e-16 from libm's value at a fifth of its instruction count.
-__device__ __forceinline__ double atan2_tab(double y, double x, const double *tab) {
-    const double m = fmax(fabs(x), fabs(y));
-    if (!(m > 0.0)) return 0.0;
-    // scale into f32 range by the exponent of m (exact)
-    const int e = (int)((__double2hiint(m) >> 20) & 0x7ff) - 1023;
-    const double sc = __hiloint2double((1023 - (e < -1000 ? -1000 : (e > 1000 ? 1000 : e))) << 20, 0);
-    const float a = __ocml_atan2pi_f32((float)(y * sc), (float)(x * sc)); // [-1, 1], units of pi
-    const int k = __builtin_amdgcn_readfirstlane((int)rintf(a * 16.0f));     // [-16, 16]; the arguments are wave-uniform
-    const double c = tab[2 * (k & 31)], s = tab[2 * (k & 31) + 1];          // scalar loads from the 512-byte global table
-    const double dot = x * c + y * s, crs = y * c - x * s;
-    const double r = crs / dot, r2 = r * r;
-    double q = -1.0 / 15.0;
-    q = fma(q, r2, 1.0 / 13.0); q = fma(q, r2, -1.0 / 11.0); q = fma(q, r2, 1.0 / 9.0);
-    q = fma(q, r2, -1.0 / 7.0); q = fma(q, r2, 1.0 / 5.0); q = fma(q, r2, -1.0 / 3.0);
-    q = fma(q, r2, 1.0);
-    return fma((double)k, 0.19634954084936207740, r * q); // k pi / 16 + atan(r)
-}
-
 // NCH chunks per frame (128 / 256), CPT chunks per thread: thread t owns chunks t, t + WG, ... so that every
 // (wavefront, u) pair is a run of 64 consecutive chunks -- a "virtual wavefront" for the scan and the flag masks.
 // Fewer, fatter threads leave fewer wavefronts idle while one of them does the fine pass.
-// BPS == 0: timing only.  BPS in {1, 2, 4, 6, 8}: timing + the receive body (see above), N = 64 (L = 80).
-template <int NCH, int CPT, int OCC, int BPS, bool GUARD>
+template <int NCH, int CPT, int OCC>
 __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
     constexpr int C = 10, WG = NCH / CPT, NW = WG / 64, VW = NCH / 64;
-    constexpr bool RX = BPS != 0;
-    constexpr int ND = GUARD ? 48 : 64, SYM_BYTES = ND * (RX ? BPS : 8) / 8, REGION_DW = 2 * SYM_BYTES; // 8 symbols, in dwords
     extern __shared__ __align__(16) unsigned char smem[];
-    const int L = RX ? 80 : p.L, W = p.W, n = p.n_lags;
+    const int L = p.L, W = p.W, n = p.n_lags;
     const int dbg = kProfile ? p.debug : 0; // the early exits / section ticks exist in the profile build only
     const int nstaged = 2 * p.n16;
     const int ns = (nstaged + C - 1) / C * C;               // whole 10-sample chunks
@@ -479,14 +427,6 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
     float *tes = be + NCH + 2;                              // [NCH] chunk energies
     float *wtot = tes + NCH;                                // [VW][4] virtual-wave totals
     unsigned long long *flg = reinterpret_cast<unsigned long long *>(wtot + 4 * VW); // [VW] flagged chunks
-    // fused receive body: constants and per-frame scalars behind the flags; 1/H and the packed image overlay the chunk
-    // arrays, which are dead once the fine pass is over
-    double *sh_turns = reinterpret_cast<double *>(flg + VW); // CFO in turns per sample
-    int *sh_i = reinterpret_cast<int *>(sh_turns + 1);      // [0] status (1 = slow list: leave every output alone) [1] offset [2] live symbols
-    cf *sh_ph = reinterpret_cast<cf *>(sh_i + 4);           // [2] exp(-j f_delta 8), exp(-j f_delta 80)
-    cf *twl = sh_ph + 2;                                    // [64] exp(-2 pi i m / 64) (spare)
-    cf *ginv = reinterpret_cast<cf *>(bq) + 64 * (threadIdx.x >> 6); // [NW][64] 1 / H, one copy per wavefront (both estimate the channel)
-    unsigned *obuf = reinterpret_cast<unsigned *>(be);      // packed decoded bytes of the frame (<= 2048 B)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -505,16 +445,12 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
 
     for (int i = nstaged + tid; i < ns + L; i += WG) raw[i] = make_float2(0.f, 0.f); // never written by the DMA
     if (tid == 0) { bq[NCH] = make_float2(0.f, 0.f); be[NCH] = 0.f; } // chunk NCH: local prefix 0 of the wavefront after the last
-    // receive-body constants of this lane (8-lane group s = symbol slot, t = lane inside it)
-    if (RX && tid < 64) twl[tid] = p.rx.tw[tid];
-    cf itrn = make_float2(0.f, 0.f);  // 1 / training[bitrev6(lane)]: the bin this lane holds after the lane FFT
-    if (RX) itrn = p.rx.inv_training[bitrev6(lane)];
     // Frames the first lags do not determine go to the device-side redo list in BATCHES: with one atomicAdd per frame on the one
     // counter, a batch in which every frame defers (late packets, empty slots) spent 1.5 ms per 131 072 frames waiting for that
     // address; a workgroup now collects up to 16 of its frames in LDS and reserves their list slots with one atomic.  Writers are
     // thread 0 (no flagged chunk) or lane 0 of the fine wavefront, in different phases of a frame, always barriers apart.
     constexpr int RB = 16;
-    int *rbuf = reinterpret_cast<int *>(flg + VW);          // !RX only: [0] pending, [1 .. RB] frames
+    int *rbuf = reinterpret_cast<int *>(flg + VW);          // [0] pending, [1 .. RB] frames
     auto redo_flush = [&]() {
         const int m = rbuf[0];
         if (m > 0) {
@@ -529,8 +465,8 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
         rbuf[0] = m + 1;
         if (m + 1 == RB) redo_flush();
     };
-    if (!RX && tid == 0) rbuf[0] = 0;
-    const bool listed = !RX && p.frame_list != nullptr;
+    if (tid == 0) rbuf[0] = 0;
+    const bool listed = p.frame_list != nullptr;
     const long long n_items = listed ? (long long)*p.frame_count : p.n_frames;
     auto frame_of = [&](long long item) -> long long { return listed ? (long long)p.frame_list[item] : item; };
     long long item = blockIdx.x;
@@ -574,7 +510,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
         }
         lds_barrier(); // B3: chunk prefixes, energies and wavefront totals visible
         const long long t2 = t1, t3 = (dbg >= 10) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        if (!RX && dbg == 2) { lds_barrier(); if (more) stage(f_next); continue; }
+        if (dbg == 2) { lds_barrier(); if (more) stage(f_next); continue; }
         float etot = 0.f; // frame energy: bounds every prefix (error margin of the coarse bound)
 #pragma unroll
         for (int wv = 0; wv < VW; ++wv) etot += wtot[wv * 4 + 2];
@@ -621,23 +557,20 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
         int gs = next_flag(0);
         if (gs < 0) { // no chunk can reach the threshold: no packet
             if (tid == 0) {
-                if (RX) {
-                    p.rx.status[f] = -2; p.rx.offset[f] = 0; p.rx.out_len[f] = 0; p.rx.f_delta[f] = 0.0;
-                    if (p.rx.metric) p.rx.metric[f] = 0.f;
-                } else if (p.defer) to_redo(f);   // nothing in the first lags: the whole search has to look
+                if (p.defer) to_redo(f);   // nothing in the first lags: the whole search has to look
                 else p.d_hat[f] = -1;
             }
             if (more) stage(f_next);   // every wave is done with the raw samples (phase 1 ended before B3)
             continue;
         }
-        if (!RX && dbg == 3) { lds_barrier(); if (more) stage(f_next); continue; }
+        if (dbg == 3) { lds_barrier(); if (more) stage(f_next); continue; }
 
         // ---- fine pass: one wavefront, the 32 chunks (320 lags) from the first flagged one; lane 2k slides forward from
         //      chunk boundary k over lags +0..+4, lane 2k+1 slides BACKWARD from boundary k+1 over lags +9..+5
         if (wave == (it & (NW - 1))) {
             const int hh = lane & 1;
             const float sgn = hh ? -1.f : 1.f;
-            long long u0 = (!RX && dbg >= 15) ? (long long)__builtin_amdgcn_s_memtime() : 0, u1 = 0, u2 = 0;
+            long long u0 = (dbg >= 15) ? (long long)__builtin_amdgcn_s_memtime() : 0, u1 = 0, u2 = 0;
             int res_d = -1;          // wave-uniform outcome: lag >= 0, -1 no packet, -2 slow list, -3 debug exit, -4 redo list
             Cand best = Cand{0.0, 1.0, 1.0, 0.0, INT_MAX};
             for (;;) {
@@ -713,8 +646,8 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                         }
                     }
                 }
-                if (!RX && dbg == 5) { res_d = -3; break; }
-                if (!RX && dbg >= 15) u1 = (long long)__builtin_amdgcn_s_memtime();
+                if (dbg == 5) { res_d = -3; break; }
+                if (dbg >= 15) u1 = (long long)__builtin_amdgcn_s_memtime();
                 const unsigned long long lo_m = __ballot(lo != INT_MAX), hi_m = __ballot(hi != INT_MAX);
                 if (lo_m == 0) { // nothing crosses in these 32 chunks: on to the next flagged chunk
                     gs = next_flag(gs + 32);
@@ -725,7 +658,7 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                 const int c_hi = hi_m ? __builtin_amdgcn_readlane(hi, __ffsll((long long)hi_m) - 1) : INT_MAX;
                 if (c_lo != c_hi) { res_d = -2; break; }                  // ambiguous crossing: redo in f64
                 const int d1 = c_lo;
-                if (!RX && p.defer && d1 + W > n - 1) { res_d = -4; break; } // the peak window reaches beyond the first lags: whole search
+                if (p.defer && d1 + W > n - 1) { res_d = -4; break; } // the peak window reaches beyond the first lags: whole search
                 const int dend = d1 + W < n - 1 ? d1 + W : n - 1;        // last lag of the peak window
                 if (dend >= (gs + 32) * C) { gs = d1 / C; continue; }    // window not covered: restart at the crossing's chunk
                 // window maximum over the trusted lags, then the candidates within 2 EPS of it (+ the untrusted ones)
@@ -757,215 +690,45 @@ __global__ __launch_bounds__(NCH / CPT, OCC) void k_sc_cf(ScFastParams p) {
                 }
                 if (cnt == 0) { res_d = -1; break; }
                 if (cnt > SC_MAXCAND) { res_d = -2; break; }
-                if (!RX && dbg == 4) { res_d = -3; break; }
-                if (!RX && dbg >= 15) u2 = (long long)__builtin_amdgcn_s_memtime();
+                if (dbg == 4) { res_d = -3; break; }
+                if (dbg >= 15) u2 = (long long)__builtin_amdgcn_s_memtime();
                 best = sc_exact_pick(raw, cand[0], cand[1], cand[2], cand[3], cnt, L, W, lane);
                 res_d = best.lag != INT_MAX ? best.lag : -1;
                 break;
             }
-            if (!RX) {
-                if (lane == 0 && res_d != -3) {
-                    if (res_d == -2) to_slow(f);
-                    else if (p.defer && (res_d == -4 || res_d == -1)) to_redo(f); // undetermined by the first lags
-                    else {
-                        p.d_hat[f] = res_d;
-                        if (res_d >= 0) p.exact[f] = ScExact{best.pr, best.pi, best.num, best.den};
-                        else p.exact[f] = ScExact{0.0, 0.0, 0.0, 1.0};
-                    }
-                }
-                if (dbg >= 15 && lane == 0) { // profiling aid: slide / select / exact time of the fine wavefront
-                    const long long u3 = (long long)__builtin_amdgcn_s_memtime();
-                    p.d_hat[f] = (int32_t)(dbg == 15 ? u1 - u0 : dbg == 16 ? u2 - u1 : u3 - u2);
-                }
-            } else if (res_d == -2) {
-                if (lane == 0) { to_slow(f); sh_i[0] = 1; }
-            } else {
-                // ---- timing -> trimmed start, length check, live symbols (receiver.rs:21-39), CFO, metric
-                int st = 0, off = 0, nsy = 0;
-                double fd = 0.0;
-                float met = 0.f;
-                if (res_d < 0) st = -2;                                   // OFDM_FRAME_NOSYNC
+            if (lane == 0 && res_d != -3) {
+                if (res_d == -2) to_slow(f);
+                else if (p.defer && (res_d == -4 || res_d == -1)) to_redo(f); // undetermined by the first lags
                 else {
-                    off = res_d - L - p.rx.backoff;
-                    if (off < 0) off = 0;
-                    const int len = (int)p.rx.frame_len - off;
-                    if (len < 10 * L) st = -1;                            // "Input not long enough, bailing early"
-                    else {
-                        const int chunks = (len + L - 1) / L - 10;        // split_into_chunks pads the tail chunk
-                        nsy = chunks < p.rx.max_symbols ? chunks : p.rx.max_symbols;
-                        if (nsy * SYM_BYTES < 16) { st = -4; nsy = 0; }
-                    }
-                    fd = atan2_tab(best.pi, best.pr, p.rx.atan_tab) / (double)L;
-                    met = (float)(best.num / best.den);
-                    if (p.rx.cfo_mode == 0) fd = 0.0;
-                    else if (p.rx.cfo_mode == 2) fd = fabs(fd);
+                    p.d_hat[f] = res_d;
+                    if (res_d >= 0) p.exact[f] = ScExact{best.pr, best.pi, best.num, best.den};
+                    else p.exact[f] = ScExact{0.0, 0.0, 0.0, 1.0};
                 }
-                const double turns = fd * 0.15915494309189533577;
-                if (lane == 0) {
-                    p.rx.status[f] = st; p.rx.offset[f] = off; p.rx.f_delta[f] = fd;
-                    if (p.rx.metric) p.rx.metric[f] = met;
-                    sh_i[0] = st; sh_i[1] = off; sh_i[2] = st == 0 ? nsy : 0; *sh_turns = turns;
-                }
-                if (st == 0 && lane < 2) sh_ph[lane] = cfo_phasor(turns, lane ? 80 : 8); // the two wave-uniform CFO steps, once per frame
+            }
+            if (dbg >= 15 && lane == 0) { // profiling aid: slide / select / exact time of the fine wavefront
+                const long long u3 = (long long)__builtin_amdgcn_s_memtime();
+                p.d_hat[f] = (int32_t)(dbg == 15 ? u1 - u0 : dbg == 16 ? u2 - u1 : u3 - u2);
             }
         }
-        lds_barrier(); // B5: the fine wavefront is done with the raw samples (RX: scalars and 1/H are in LDS)
-        if (!RX) {
-            if (dbg >= 10 && dbg < 15 && tid == 0) { // profiling aid: per-frame section time (s_memtime ticks) instead of the timing result
-                const long long t5 = (long long)__builtin_amdgcn_s_memtime();
-                const long long dt[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4};
-                p.d_hat[f] = (int32_t)dt[dbg - 10 < 5 ? dbg - 10 : 4];
-            }
-            if (more) stage(f_next);
-            continue;
+        lds_barrier(); // B5: the fine wavefront is done with the raw samples
+        if (dbg >= 10 && dbg < 15 && tid == 0) { // profiling aid: per-frame section time (s_memtime ticks) instead of the timing result
+            const long long t5 = (long long)__builtin_amdgcn_s_memtime();
+            const long long dt[5] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4};
+            p.d_hat[f] = (int32_t)dt[dbg - 10 < 5 ? dbg - 10 : 4];
         }
-        const long long t5 = (dbg >= 20) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        // ---- receive body.  Both wavefronts estimate the channel (cheap: ONE transform per frame), then wavefront w takes
-        //      the groups w, w + NW, ... of 8 data symbols
-        const int st_f = __builtin_amdgcn_readfirstlane(sh_i[0]);
-        const int off_f = __builtin_amdgcn_readfirstlane(sh_i[1]);
-        const int ns_f = __builtin_amdgcn_readfirstlane(sh_i[2]);
-        if (st_f == 0 && 8 * wave < ns_f) {
-            const double turns = *sh_turns;
-            cf *lsrc = raw + off_f;
-            const bool cfo_on = turns != 0.0;
-            int lane_ = lane;
-            asm volatile("" : "+v"(lane_)); // the per-lane constants below are rebuilt per frame on purpose: hoisted out of the
-                                            // frame loop they stay live across the timing search and spill
-            const int s = lane_ >> 3, t = lane_ & 7, wr = 9 * t; // 8-lane group s = symbol slot, t = lane inside it; wr = swz(8 t)
-            const cf st8 = sh_ph[0];
-            {   // estimate_channel (receiver.rs:212-229): H = mean_b FFT(block_b) / training = FFT(mean_b block_b) / training.
-                // Lane n sums sample n of the 5 derotated training blocks, the wavefront transforms the 64 sums (one point
-                // per lane), and lane l ends up with bin bitrev6(l): H, then 1/H into this wavefront's LDS table.
-                cf tws[6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const int h = 32 >> q;
-                    tws[q] = (lane_ & h) ? twl[(lane_ & (h - 1)) << q] : make_float2(1.f, 0.f);
-                }
-                const int nb = 5 * 80 + 16 + lane_;
-                cf x4 = lsrc[nb + 320], x3 = lsrc[nb + 240], x2 = lsrc[nb + 160], x1 = lsrc[nb + 80], x0 = lsrc[nb];
-                cf acc;
-                if (cfo_on) { // sum_b x_b e^{-j phi (nb + 80 b)}: Horner in the 80-sample step, then this lane's phasor
-                    const cf s80 = sh_ph[1], q0 = cfo_phasor(turns, nb);
-                    acc = cadd(cmul(x4, s80), x3);
-                    acc = cadd(cmul(acc, s80), x2);
-                    acc = cadd(cmul(acc, s80), x1);
-                    acc = cadd(cmul(acc, s80), x0);
-                    acc = cmul(acc, q0);
-                } else acc = cadd(cadd(cadd(x4, x3), cadd(x2, x1)), x0);
-                acc = lane_fft64(acc, lane_, tws);
-                cf h = cmul(acc, itrn);
-                h = make_float2(h.x * 0.2f, h.y * 0.2f);
-                const float rn = __builtin_amdgcn_rcpf(h.x * h.x + h.y * h.y);
-                ginv[bitrev6(lane_)] = make_float2(h.x * rn, -h.y * rn); // 1 / H
-            }
-            cf w[7];
-            int bitoff[8];                  // bit offset of bin t + 8 m inside an 8-symbol packed image, -1 = not a data bin
-#pragma unroll
-            for (int r = 1; r < 8; ++r) w[r - 1] = twl[r * t];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int c = t + 8 * m;
-                const int q = GUARD ? data_classes_below64(c) : c;
-                bitoff[m] = (carrier_class64(c, GUARD) == 0) ? (s * ND + q) * BPS : -1;
-            }
-            for (int k0 = 8 * wave; k0 < ns_f; k0 += 8 * NW) {
-                const bool act = k0 + s < ns_f;                   // this lane group's symbol is live
-                const int n0 = (10 + k0 + s) * 80 + 16 + t;       // sample id (from the trimmed start) of this lane's first point
-                cf *buf = lsrc + (10 + k0 + s) * 80;              // the symbol's own LDS slot doubles as its transpose slab
-                cf v[8];
-                if (act) {
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) v[m] = lsrc[n0 + 8 * m]; // past the capture: zeros (pad_chunk, receiver.rs:203-210)
-                    if (cfo_on) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50)
-                        cf ph = cfo_phasor(turns, n0);
-#pragma unroll
-                        for (int m = 0; m < 8; ++m) { v[m] = cmul(v[m], ph); ph = cmul(ph, st8); }
-                    }
-                } else {
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
-                }
-                bfly8<false>(v);
-                if (act) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) buf[wr ^ r] = v[r];
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) v[m] = buf[8 * m + (t ^ m)];
-                }
-#pragma unroll
-                for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
-                bfly8<false>(v);
-#pragma unroll
-                for (int m = 0; m < 8; ++m) v[m] = cmul(v[m], ginv[t + 8 * m]); // equalise (receiver.rs:68-70); 1/H read at use: 16 fewer live registers
-                cf rot = make_float2(1.f, 0.f);
-                if (GUARD) { // decode_block (receiver.rs:106-145): mean of the 4 pilot angles, rotate by -phase
-                    cf pv = make_float2(1.f, 0.f);
-                    pv = (t == 6) ? v[0] : pv;
-                    pv = (t == 1) ? v[3] : pv;
-                    pv = (t == 7) ? v[4] : pv;
-                    pv = (t == 2) ? v[7] : pv;
-                    const float trn = sum8_lanes(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.125f; // mean pilot angle in turns
-                    rot = make_float2(__builtin_amdgcn_cosf(trn), -__builtin_amdgcn_sinf(trn)); // applied inside the demapper
-                }
-                unsigned *img = obuf + k0 * (SYM_BYTES / 4);      // this group's part of the frame's packed image
-                for (int i = lane; i < REGION_DW; i += 64) img[i] = 0u;
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    if (bitoff[m] >= 0 && act) {
-                        const unsigned idx = GUARD ? demap_point_rot(v[m], rot, BPS) : demap_point(v[m], BPS);
-                        const int wd = bitoff[m] >> 5, shf = bitoff[m] & 31;
-                        atomicOr(&img[wd], idx << shf);
-                        if (BPS > 1 && (32 % BPS) != 0) { // a field may straddle two dwords (only for 6-bit fields)
-                            if (shf + BPS > 32) atomicOr(&img[wd + 1], idx >> (32 - shf));
-                        }
-                    }
-                }
-            }
-        }
-        lds_barrier(); // B6: the packed image is complete; nobody reads the raw samples any more
-        const long long t6 = (dbg >= 20) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        if (more) stage(f_next);                                  // next frame's DMA flies while this one is finished
-        for (int i = nstaged + tid; i < ns + L; i += WG) raw[i] = make_float2(0.f, 0.f); // a tail symbol's slab may have spilled into the zero pad
-        if (st_f == 0) { // ---- length header, truncate (receiver.rs:85-95) [, Hamming(7,4)], bytes to their final place
-            const unsigned lo0 = obuf[0], lo1 = obuf[1], hi0 = obuf[2], hi1 = obuf[3]; // bincode fixint little-endian u128
-            const int body = ns_f * SYM_BYTES - 16;
-            const int keep = ((hi0 | hi1 | lo1) == 0u && lo0 < (unsigned)body) ? (int)lo0 : body; // Vec::truncate
-            unsigned *fo = reinterpret_cast<unsigned *>(p.rx.out + f * p.rx.out_stride);
-            if (!p.rx.ecc) {
-                const int nd = keep >> 2;
-                for (int i = tid; i < nd; i += WG) fo[i] = obuf[4 + i];
-                if (tid < (keep & 3)) reinterpret_cast<unsigned char *>(fo)[4 * nd + tid] = (unsigned char)(obuf[4 + nd] >> (8 * tid));
-                if (tid == 0) p.rx.out_len[f] = keep;
-            } else {
-                const int blocks = keep / 7;
-                const uint8_t *cw = reinterpret_cast<const uint8_t *>(obuf + 4);
-                for (int b = tid; b < blocks; b += WG) {
-                    unsigned fixed = 0;
-                    uint8_t d4[4];
-                    ham_decode_block(cw + 7 * b, d4, fixed);
-                    fo[b] = (unsigned)d4[0] | ((unsigned)d4[1] << 8) | ((unsigned)d4[2] << 16) | ((unsigned)d4[3] << 24);
-                }
-                if (tid == 0) p.rx.out_len[f] = blocks * 4;
-            }
-        } else if (st_f < 0 && tid == 0) p.rx.out_len[f] = 0;
-        if (dbg >= 20 && tid == 0 && p.rx.metric) { // profiling aid (OFDM_SC_DEBUG=20..26): section ticks instead of the metric
-            const long long t7 = (long long)__builtin_amdgcn_s_memtime();
-            const long long dt[7] = {t1 - t0, t3 - t1, t4 - t3, t5 - t4, t6 - t5, t7 - t6, t7 - t0};
-            p.rx.metric[f] = (float)dt[dbg - 20 < 7 ? dbg - 20 : 6];
-        }
+        if (more) stage(f_next);
+        continue;
     }
-    if (!RX && p.defer) { // the frames still waiting in this workgroup's LDS batch
+    if (p.defer) { // the frames still waiting in this workgroup's LDS batch
         lds_barrier();
         if (tid == 0) redo_flush();
     }
 }
-static size_t sc_cf_lds_bytes(int L, int nch, long long frame_len, bool rx) { // raw samples + chunk prefixes, energies, flags
+static size_t sc_cf_lds_bytes(int L, int nch, long long frame_len) { // raw samples + chunk prefixes, energies, flags
     long long ns = ((frame_len + 1) / 2 * 2 + 9) / 10 * 10;
     if (ns > (long long)nch * 10) ns = (long long)nch * 10;
     return (size_t)(ns + L) * sizeof(float2) + (size_t)(nch + 2) * (sizeof(float2) + sizeof(float)) + (size_t)nch * sizeof(float) +
-           16 * sizeof(float) + 64 + 16 + (rx ? 48 + 64 * sizeof(float2) : 80 /* the redo batch: count + 16 frames */);
+           16 * sizeof(float) + 64 + 16 + 80 /* the redo batch: count + 16 frames */;
 }
 
 // chunks per frame (128 / 256, 10 samples each): the smallest tile that covers the searched lags plus the window
@@ -980,40 +743,20 @@ bool sc_fast_ok(const ScParams &p) {
     return p.mode == 0 && sc_fast_pick_nch(p) != 0 && p.L % 10 == 0 && p.W % 10 == 0 && p.W + 20 <= 320 &&
            (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0;
 }
-// the fused receive body needs N = 64 (L = 80), the WHOLE frame inside the 256-chunk tile, 4-byte aligned output rows,
-// whole-dword symbols and a packed frame image that fits over the chunk arrays (2 KiB)
-bool sc_rx_fused_ok(const ScParams &p, const ScRxFused &rx) {
-    if (!sc_fast_ok(p) || p.L != 80 || p.frame_len > 2560) return false;
-    const int sym_bytes = (rx.guard ? 48 : 64) * rx.bps / 8;
-    if (sym_bytes % 4 != 0 || rx.max_symbols <= 0) return false;
-    if ((long long)((rx.max_symbols + 7) / 8 * 8) * sym_bytes > 2048) return false;
-    if ((reinterpret_cast<uintptr_t>(rx.out) & 3) || (rx.out_stride & 3)) return false;
-    return rx.out && rx.out_len && rx.status && rx.offset && rx.f_delta && rx.tw && rx.inv_training && rx.atan_tab;
-}
 size_t sc_fast_workspace_bytes(long long n_frames, int /*W*/) {
     return (size_t)n_frames * (sizeof(ScExact) + 2 * sizeof(int32_t)) + 128; // exact sums + slow list + redo list (+ their counters)
 }
 
-template <int BPS> static void launch_sc_rx(bool guard, dim3 grid, size_t lds, hipStream_t st, const ScFastParams &q) {
-    if (guard) hipLaunchKernelGGL((k_sc_cf<256, 2, 3, BPS, true>), grid, dim3(128), lds, st, q);
-    else hipLaunchKernelGGL((k_sc_cf<256, 2, 3, BPS, false>), grid, dim3(128), lds, st, q);
-}
-
 // p.mode == 0, p.tiles_per_frame == 1.  workspace: sc_fast_workspace_bytes(n_frames) bytes of device memory.
-// rx != nullptr (sc_rx_fused_ok): the fused timing + receive kernel; the frames it could not settle are left on the
-// device-side slow list (*slow_list / *slow_count, timing redone here by k_sc_tile) for the caller's list-mode kernels.
-hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st, const ScRxFused *rx,
-                       const int32_t **slow_list_out, const int32_t **slow_count_out) {
+hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st) {
     if (p.n_frames <= 0) return hipSuccess;
-    const int nch = rx ? 256 : sc_fast_pick_nch(p);
+    const int nch = sc_fast_pick_nch(p);
     ScExact *exact = reinterpret_cast<ScExact *>(workspace);
     int32_t *slow_count = reinterpret_cast<int32_t *>(exact + p.n_frames);
     int32_t *slow_list = slow_count + 4;
     int32_t *redo_count = slow_list + p.n_frames;
     int32_t *redo_list = redo_count + 4;
-    if (slow_list_out) *slow_list_out = slow_list;
-    if (slow_count_out) *slow_count_out = slow_count;
-    if (p.stats) { p.stats->slow_count = slow_count; p.stats->redo_count = nullptr; }
+    bool used_redo = false;
     hipError_t e = hipMemsetAsync(slow_count, 0, 16, st);
     if (e != hipSuccess) return e;
     ScFastParams q;
@@ -1022,7 +765,7 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     const long long tile_n = (long long)nch * 10;
     long long stage = p.frame_len < tile_n ? p.frame_len : tile_n;
     const long long needed = (p.n_lags + p.W + p.L + 10 + 1) & ~1LL; // the last searched lag's window, plus the slide's reach
-    if (needed < stage && !rx) stage = needed;                        // bounded searches stage (and sum) only what they use
+    if (needed < stage) stage = needed;                        // bounded searches stage (and sum) only what they use
     q.n16 = (int)(stage / 2);
     q.n_lags = (int)p.n_lags; q.L = p.L; q.W = p.W;
     const Tuning &tu = tuning_or_default(p.tune);
@@ -1030,15 +773,9 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     q.thr_lo = (float)(p.threshold * (1.0 - (double)SC_EPS));
     q.thr_hi = (float)(p.threshold * (1.0 + (double)SC_EPS));
     q.d_hat = p.d_hat; q.slow_list = slow_list; q.slow_count = slow_count; q.exact = exact;
-    if (rx) {
-        q.rx.frame_len = p.frame_len; q.rx.backoff = rx->backoff; q.rx.cfo_mode = rx->cfo_mode; q.rx.max_symbols = rx->max_symbols;
-        q.rx.ecc = rx->ecc; q.rx.tw = rx->tw; q.rx.inv_training = rx->inv_training; q.rx.atan_tab = rx->atan_tab;
-        q.rx.out = rx->out; q.rx.out_stride = rx->out_stride; q.rx.out_len = rx->out_len; q.rx.status = rx->status;
-        q.rx.offset = rx->offset; q.rx.f_delta = rx->f_delta; q.rx.metric = rx->metric;
-    }
     // persistent over the frames; workgroups per CU bounded by LDS (22.5 KB for a 2176-sample frame -> 7)
     const int per_cu_cap = tu.sc_wg_per_cu > 0 ? tu.sc_wg_per_cu : 7; // tuning knob
-    const size_t lds = sc_cf_lds_bytes(p.L, nch, stage, rx != nullptr);
+    const size_t lds = sc_cf_lds_bytes(p.L, nch, stage);
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
     if (per_cu > per_cu_cap) per_cu = per_cu_cap;
     if (per_cu < 1) per_cu = 1;
@@ -1046,20 +783,9 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     const long long gcap = tu.grid_cap > 0 ? tu.grid_cap : (1LL << 40);
     if (grid > gcap) grid = gcap;
     if (grid > p.n_frames) grid = p.n_frames;
-    if (!rx && !tu.no_sc80 && sc80_ok(p)) {
+    if (!tu.no_sc80 && sc80_ok(p)) {
         // N = 64 (L = 80, W = 240): every lag exactly, one streaming pass that stops when the peak window has closed (kernels_sc80.hip)
         if ((e = launch_sc80(p, exact, slow_list, slow_count, num_cu, st)) != hipSuccess) return e;
-    } else if (rx) {
-        if (per_cu > 6) { per_cu = 6; grid = (long long)num_cu * per_cu; if (grid > gcap) grid = gcap; if (grid > p.n_frames) grid = p.n_frames; } // 3 waves per SIMD
-        trace_add(p.trace, "k_sc_cf<rx>");
-        switch (rx->bps) {
-        case 1: launch_sc_rx<1>(rx->guard != 0, dim3((unsigned)grid), lds, st, q); break;
-        case 2: launch_sc_rx<2>(rx->guard != 0, dim3((unsigned)grid), lds, st, q); break;
-        case 4: launch_sc_rx<4>(rx->guard != 0, dim3((unsigned)grid), lds, st, q); break;
-        case 6: launch_sc_rx<6>(rx->guard != 0, dim3((unsigned)grid), lds, st, q); break;
-        case 8: launch_sc_rx<8>(rx->guard != 0, dim3((unsigned)grid), lds, st, q); break;
-        default: return hipErrorInvalidValue;
-        }
     } else if (nch == 256) {
         // Two-phase search.  The detector is threshold-then-peak: once the first crossing d1 is known nothing after lag d1 + W can
         // change the answer, so the first `first` lags DETERMINE the result of every frame whose crossing and whole peak window lie
@@ -1072,14 +798,14 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         bool two_phase = first > 0 && p.n_lags >= 2LL * first && (long long)128 * 10 - p.W - p.L - 12 >= first && first > p.W + 1;
         if (two_phase) {
             if ((e = hipMemsetAsync(redo_count, 0, 16, st)) != hipSuccess) return e;
-            if (p.stats) p.stats->redo_count = redo_count;
+            used_redo = true;
             ScFastParams q1 = q;
             q1.n_lags = first; q1.defer = 1;
             long long stage1 = (first + p.W + p.L + 10 + 1) & ~1LL;
             if (stage1 > p.frame_len) stage1 = p.frame_len & ~1LL;
             if (stage1 > 1280) stage1 = 1280;
             q1.n16 = (int)(stage1 / 2);
-            const size_t lds1 = sc_cf_lds_bytes(p.L, 128, stage1, false);
+            const size_t lds1 = sc_cf_lds_bytes(p.L, 128, stage1);
             long long pc = (long long)(160 * 1024) / (long long)lds1;
             if (pc > 10) pc = 10;
             long long g1 = (long long)num_cu * pc;
@@ -1092,14 +818,14 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
                 long long g1w = (long long)num_cu * pc1;
                 if (g1w > gcap) g1w = gcap;
                 if (g1w > p.n_frames) g1w = p.n_frames;
-                hipLaunchKernelGGL((k_sc_cf<128, 2, 4, 0, false>), dim3((unsigned)g1w), dim3(64), lds1, st, q1);
+                hipLaunchKernelGGL((k_sc_cf<128, 2, 4>), dim3((unsigned)g1w), dim3(64), lds1, st, q1);
             } else
-            hipLaunchKernelGGL((k_sc_cf<128, 1, 5, 0, false>), dim3((unsigned)g1), dim3(128), lds1, st, q1);
+            hipLaunchKernelGGL((k_sc_cf<128, 1, 5>), dim3((unsigned)g1), dim3(128), lds1, st, q1);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             q.frame_list = redo_list; q.frame_count = redo_count;
             trace_add(p.trace, "k_sc_cf<256,list>");
         } else trace_add(p.trace, "k_sc_cf<256>");
-        hipLaunchKernelGGL((k_sc_cf<256, 2, 4, 0, false>), dim3((unsigned)grid), dim3(128), lds, st, q); // <= 7 x 2 waves per CU
+        hipLaunchKernelGGL((k_sc_cf<256, 2, 4>), dim3((unsigned)grid), dim3(128), lds, st, q); // <= 7 x 2 waves per CU
     } else { // 128-chunk tile (bounded searches): 128 threads, one chunk each, up to 10 workgroups per CU (measured best)
         per_cu = (long long)(160 * 1024) / (long long)lds;
         if (per_cu > 10) per_cu = 10;
@@ -1113,16 +839,14 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
             grid = (long long)num_cu * per_cu;
             if (grid > gcap) grid = gcap;
             if (grid > p.n_frames) grid = p.n_frames;
-            hipLaunchKernelGGL((k_sc_cf<128, 2, 4, 0, false>), dim3((unsigned)grid), dim3(64), lds, st, q);
+            hipLaunchKernelGGL((k_sc_cf<128, 2, 4>), dim3((unsigned)grid), dim3(64), lds, st, q);
         } else
-        hipLaunchKernelGGL((k_sc_cf<128, 1, 5, 0, false>), dim3((unsigned)grid), dim3(128), lds, st, q);
+        hipLaunchKernelGGL((k_sc_cf<128, 1, 5>), dim3((unsigned)grid), dim3(128), lds, st, q);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (!rx) {
-        hipLaunchKernelGGL(k_sc_post, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, p.d_hat, exact, p.n_frames, p.L,
-                           p.f_delta, p.metric);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
+    hipLaunchKernelGGL(k_sc_post, dim3((unsigned)((p.n_frames + 255) / 256)), dim3(256), 0, st, p.d_hat, exact, p.n_frames, p.L,
+                       p.f_delta, p.metric);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     // frames the filter could not settle: all-f64 kernel over the device-side list (usually empty)
     ScParams s = p;
     s.slow_list = slow_list; s.slow_count = slow_count; s.tiles_per_frame = 1; s.mode = 0;
@@ -1134,7 +858,16 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     long long g2 = p.n_frames < 512 ? p.n_frames : 512;
     trace_add(p.trace, "k_sc_tile<list>");
     hipLaunchKernelGGL(k_sc_tile, dim3((unsigned)g2), dim3(SC_WG), lds2, st, s);
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (p.stats && p.stats->dev) { // the counters leave the workspace: it may be regrown or reused before anyone asks for them
+        if ((e = hipMemcpyAsync(p.stats->dev, slow_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+        p.stats->has_slow = true;
+        if (used_redo) {
+            if ((e = hipMemcpyAsync(p.stats->dev + 1, redo_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+            p.stats->has_redo = true;
+        }
+    }
+    return hipSuccess;
 }
 
 __global__ void k_sc_min_cross(const long long *cross, int tiles, long long n_frames, int32_t *d1) {

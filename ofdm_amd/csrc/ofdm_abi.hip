@@ -225,7 +225,7 @@ int ofdm_destroy(ofdm_ctx *c) {
     if (c->d_tw) hipFree(c->d_tw);
     if (c->d_inv_trn) hipFree(c->d_inv_trn);
     if (c->d_header) hipFree(c->d_header);
-    if (c->d_atan_tab) hipFree(c->d_atan_tab);
+    if (c->d_stats) hipFree(c->d_stats);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -250,7 +250,7 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
     if (p->cfo_mode < OFDM_CFO_OFF || p->cfo_mode > OFDM_CFO_ABS) return OFDM_ERR_INVALID;
     if (!(p->sync_threshold > 0.f && p->sync_threshold <= 1.f)) return OFDM_ERR_INVALID;
     if (p->sync_mode != OFDM_SYNC_SCHMIDL_COX && p->sync_mode != OFDM_SYNC_REFERENCE) return OFDM_ERR_INVALID;
-    if (p->rx_path < OFDM_RX_AUTO || p->rx_path > OFDM_RX_ONE_PASS) return OFDM_ERR_INVALID;
+    if (p->rx_path != OFDM_RX_AUTO && p->rx_path != OFDM_RX_STAGED) return OFDM_ERR_INVALID; // (2 was the one-pass kernel of rounds 2-4: removed)
     for (int r : p->reserved) if (r != 0) return OFDM_ERR_INVALID;
 
     int ndev = 0;
@@ -266,8 +266,6 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
     c->prm = *p;
     c->device = device;
     c->trace.reset();
-    // AUTO = the staged chain: measured on MI355X it still beats the one-pass kernel by a few per cent
-    c->tune.one_pass_rx = p->rx_path == OFDM_RX_ONE_PASS;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc = OFDM_OK;
     do {
@@ -307,12 +305,9 @@ int ofdm_create(const ofdm_params *p, const double *preamble, const double *trai
         for (auto &v : hdr) { hmax = std::fmax(hmax, v.x); hmax = std::fmax(hmax, v.y); }
         c->header_max = hmax;
 
-        double atab[64];
-        for (int k = 0; k < 32; k++) { atab[2 * k] = std::cos(kPi * k / 16.0); atab[2 * k + 1] = std::sin(kPi * k / 16.0); }
         if (hipMalloc(&c->d_tw, sizeof(float2) * N) != hipSuccess || hipMalloc(&c->d_inv_trn, sizeof(float2) * N) != hipSuccess ||
             hipMalloc(&c->d_header, sizeof(float2) * 10 * S) != hipSuccess ||
-            hipMalloc(&c->d_atan_tab, sizeof(atab)) != hipSuccess) { rc = OFDM_ERR_NOMEM; break; }
-        if (hipMemcpy(c->d_atan_tab, atab, sizeof(atab), hipMemcpyHostToDevice) != hipSuccess) { rc = OFDM_ERR_HIP; break; }
+            hipMalloc(&c->d_stats, 2 * sizeof(int32_t)) != hipSuccess) { rc = OFDM_ERR_NOMEM; break; }
         if (hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(c->d_inv_trn, inv.data(), sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(c->d_header, hdr.data(), sizeof(float2) * 10 * S, hipMemcpyHostToDevice) != hipSuccess) { rc = OFDM_ERR_HIP; break; }
@@ -350,33 +345,10 @@ int ofdm_last_hip_error(const ofdm_ctx *c) { return c ? c->last_hip : 0; }
 
 namespace {
 struct TuneKey { const char *name; int Tuning::*field; bool profile_only; };
-const TuneKey kTuneKeys[] = {
-    {"one_pass_rx", &Tuning::one_pass_rx, false},
-    {"no_sc80", &Tuning::no_sc80, false},
-    {"sc80_depth", &Tuning::sc80_depth, false},
-    {"no_sc_stream", &Tuning::no_sc_stream, false},
-    {"no_sc_big", &Tuning::no_sc_big, false},
-    {"no_fast64", &Tuning::no_fast64, false},
-    {"no_demod4096", &Tuning::no_demod4096, false},
-    {"no_mid_kernels", &Tuning::no_mid_kernels, false},
-    {"no_rxframe1024", &Tuning::no_rxframe1024, false},
-    {"no_txframe64", &Tuning::no_txframe64, false},
-    {"no_rx1024_finish", &Tuning::no_rx1024_finish, false},
-    {"no_rxframe64_split", &Tuning::no_rxframe64_split, false},
-    {"tx_waves", &Tuning::tx_waves, false},
-    {"txframe_keep_steps", &Tuning::txframe_keep_steps, false},
-    {"txframe_rewrite", &Tuning::txframe_rewrite, false},
-    {"sc_wg_per_cu", &Tuning::sc_wg_per_cu, false},
-    {"sc_first_lags", &Tuning::sc_first_lags, false},
-    {"sc128_one_wave", &Tuning::sc128_one_wave, false},
-    {"demod64_wg_per_cu", &Tuning::demod64_wg_per_cu, false},
-    {"demod64_burst", &Tuning::demod64_burst, false},
-    {"demod64_narrow_stores", &Tuning::demod64_narrow_stores, false},
-    {"scb_two_segments", &Tuning::scb_two_segments, false},
-    {"scb_big_tiles", &Tuning::scb_big_tiles, false},
-    {"debug_demod64", &Tuning::debug_demod64, true},
-    {"debug_sc", &Tuning::debug_sc, true},
-    {"debug_tx", &Tuning::debug_tx, true},
+const TuneKey kTuneKeys[] = { // the laboratory keys: ofdm_hip_tuning.h (private); the public ones are handled by name below
+#define OFDM_TUNE_KEY(name, field, prof) {name, &Tuning::field, prof},
+#include "ofdm_hip_tuning.h"
+#undef OFDM_TUNE_KEY
 };
 } // namespace
 
@@ -403,9 +375,10 @@ int ofdm_get_tuning(const ofdm_ctx *c, const char *key, int64_t *value) {
     if (std::strcmp(key, "profile_build") == 0) { *value = kProfile ? 1 : 0; return OFDM_OK; }
     if (std::strcmp(key, "stat_sc_slow_frames") == 0 || std::strcmp(key, "stat_sc_redo_frames") == 0) {
         // counters of the LAST Schmidl-Cox search of this context (synchronises its stream); -1 when that search kept no such list
-        const int32_t *src = key[8] == 's' ? c->sc_stats.slow_count : c->sc_stats.redo_count;
+        const bool slow = key[8] == 's';
         *value = -1;
-        if (!src) return OFDM_OK;
+        if (!c->sc_stats.dev || !(slow ? c->sc_stats.has_slow : c->sc_stats.has_redo)) return OFDM_OK;
+        const int32_t *src = c->sc_stats.dev + (slow ? 0 : 1);
         DeviceGuard dev_guard(c->device);
         int32_t v = 0;
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, src, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return OFDM_ERR_HIP;
@@ -597,6 +570,7 @@ static bool sc_make_params(ofdm_ctx *c, const float2 *in, int64_t n_frames, int6
     p.tiles_per_frame = 1; p.mode = 0;
     p.tune = &c->tune; p.trace = &c->trace;
     c->sc_stats = ScStats();
+    c->sc_stats.dev = c->d_stats;
     p.stats = &c->sc_stats;
     return true;
 }
@@ -812,9 +786,27 @@ int ofdm_tx_encode_batch(ofdm_ctx *c, const uint8_t *payload, int64_t n_frames, 
     return OFDM_OK;
 }
 
+namespace { struct KnownSync { int32_t d_hat; double f_delta; float metric; }; }
+static int rx_decode_impl(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                          int64_t n_lags, int32_t max_symbols, uint8_t *out, int64_t out_stride, int32_t *out_len,
+                          int32_t *status, int32_t *offset, double *f_delta, float *metric, const KnownSync *known);
+
 int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
                          int64_t n_lags, int32_t max_symbols, uint8_t *out, int64_t out_stride, int32_t *out_len,
                          int32_t *status, int32_t *offset, double *f_delta, float *metric) {
+    return rx_decode_impl(c, in, n_frames, frame_stride, frame_len, n_lags, max_symbols, out, out_stride, out_len, status, offset, f_delta,
+                          metric, nullptr);
+}
+int ofdm_abi_rx_decode_known(ofdm_ctx *c, const ofdm_fc32 *in, int64_t frame_len, int32_t d_hat, double f_delta, float metric,
+                             int32_t max_symbols, uint8_t *out, int64_t out_stride, int32_t *out_len, int32_t *status, int32_t *offset,
+                             double *f_delta_out, float *metric_out) {
+    const KnownSync k{d_hat, f_delta, metric};
+    return rx_decode_impl(c, in, 1, frame_len, frame_len, 0, max_symbols, out, out_stride, out_len, status, offset, f_delta_out, metric_out, &k);
+}
+
+static int rx_decode_impl(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                          int64_t n_lags, int32_t max_symbols, uint8_t *out, int64_t out_stride, int32_t *out_len,
+                          int32_t *status, int32_t *offset, double *f_delta, float *metric, const KnownSync *known) {
     if (!c || n_frames < 0 || frame_len <= 0 || max_symbols <= 0) return OFDM_ERR_INVALID;
     if (n_frames && (!in || !out || !out_len || !status)) return OFDM_ERR_INVALID;
     if (n_frames > 1 && frame_stride <= 0) return OFDM_ERR_INVALID;
@@ -837,47 +829,15 @@ int ofdm_rx_decode_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int
     int32_t *offs = offset ? offset : (int32_t *)w_off;
     double *fd = f_delta ? f_delta : (double *)w_fd;
     const float2 *x = reinterpret_cast<const float2 *>(in);
-    // 0. N = 64 frames that fit one LDS tile: timing, CFO, channel estimate, demod and the finish in ONE kernel and one
-    //    pass over HBM (k_sc_cf<..., BPS>, kernels_sync.hip).  The few frames its f32 filter cannot settle come back on
-    //    a device-side list and take the list-mode kernels below.
-    if (N == 64 && c->prm.sync_mode == OFDM_SYNC_SCHMIDL_COX) {
-        // ofdm_params.rx_path = OFDM_RX_ONE_PASS (or ofdm_set_tuning "one_pass_rx"): the one-pass kernel moves half the HBM bytes
-        // of the staged chain but is VALU-issue bound with 12 wavefronts per CU (its LDS footprint); see DESIGN.md section 5.2.
-        const bool off = !c->tune.one_pass_rx;
-        ScParams scp;
-        ScRxFused rx;
-        rx.bps = c->prm.modulation; rx.guard = c->prm.guard_bands; rx.backoff = c->prm.sync_backoff; rx.cfo_mode = c->prm.cfo_mode;
-        rx.max_symbols = max_symbols; rx.ecc = c->prm.ecc; rx.tw = c->d_tw; rx.inv_training = c->d_inv_trn; rx.atan_tab = c->d_atan_tab;
-        rx.out = out; rx.out_stride = out_stride; rx.out_len = out_len; rx.status = status; rx.offset = offs; rx.f_delta = fd;
-        rx.metric = metric;
-        if (!off && sc_make_params(c, x, n_frames, frame_stride, frame_len, n_lags, (int32_t *)w_dhat, fd, metric, scp) &&
-            sc_rx_fused_ok(scp, rx)) {
-            void *wsp;
-            if ((rc = ws_get(c, 6, sc_fast_workspace_bytes(n_frames, scp.W), &wsp))) return rc;
-            if (c->prm.ecc != OFDM_ECC_NONE && (rc = ws_get(c, 5, (size_t)raw_stride * (size_t)n_frames, &w_raw))) return rc;
-            const int32_t *slow_list = nullptr, *slow_count = nullptr;
-            HIP_TRY(c, run_sc_fast(scp, wsp, c->num_cu, c->stream, &rx, &slow_list, &slow_count));
-            // slow-list frames (k_sc_tile has just redone their timing in f64): prepare -> receive body -> finish
-            c->trace.add("k_rx_prepare<list>");
-            HIP_TRY(c, run_rx_prepare(n_frames, (const int32_t *)w_dhat, fd, frame_len, c->S(), c->prm.sync_backoff, c->prm.cfo_mode,
-                                      max_symbols, bps_bytes, status, offs, (int32_t *)w_nsym, c->stream, slow_list, slow_count));
-            SymParams p = base_params(c);
-            p.in = x; p.n_frames = n_frames; p.frame_stride = frame_stride; p.frame_len = frame_len;
-            p.offset = offs; p.f_delta = fd; p.nsym_frame = (const int32_t *)w_nsym;
-            const bool fin = c->prm.ecc == OFDM_ECC_NONE;
-            p.out_bytes = fin ? out : (uint8_t *)w_raw; p.out_stride = fin ? out_stride : raw_stride;
-            HIP_TRY(c, fin ? run_rxframe64(p, nullptr, c->stream, c->num_cu, out, out_stride, out_len, slow_list, slow_count)
-                           : run_rxframe64(p, nullptr, c->stream, c->num_cu, nullptr, 0, nullptr, slow_list, slow_count));
-            if (!fin) {
-                c->trace.add("k_rx_finish<list>");
-                HIP_TRY(c, run_rx_finish((const uint8_t *)w_raw, raw_stride, n_frames, status, (const int32_t *)w_nsym, bps_bytes,
-                                         c->prm.ecc, out, out_stride, out_len, c->stream, slow_list, slow_count));
-            }
-            return OFDM_OK;
-        }
-    }
     if ((rc = ws_get(c, 5, (size_t)raw_stride * (size_t)n_frames, &w_raw))) return rc;
-    if (c->prm.sync_mode == OFDM_SYNC_REFERENCE) {
+    if (known) {
+        // 1k. the caller brings the timing of the one capture (ofdm_rx_decode_long with lag_lo > 0)
+        if (n_frames != 1 || c->prm.sync_mode != OFDM_SYNC_SCHMIDL_COX) return OFDM_ERR_INVALID;
+        c->trace.add("k_set_sync+k_rx_prepare");
+        HIP_TRY(c, run_set_sync((int32_t *)w_dhat, fd, metric, known->d_hat, known->f_delta, known->metric, c->stream));
+        HIP_TRY(c, run_rx_prepare(n_frames, (const int32_t *)w_dhat, fd, frame_len, c->S(), c->prm.sync_backoff,
+                                  c->prm.cfo_mode, max_symbols, bps_bytes, status, offs, (int32_t *)w_nsym, c->stream));
+    } else if (c->prm.sync_mode == OFDM_SYNC_REFERENCE) {
         // 1r. the reference's own detector (src/receiver.rs:20-25): cross-correlation with the locking signal, offset =
         //     idx_max - N (= lag - 1), then frequency_correction on chunks 3 and 4 (receiver.rs:39; always |.|)
         if (frame_len > 0x3fffffff) return OFDM_ERR_UNSUPPORTED;

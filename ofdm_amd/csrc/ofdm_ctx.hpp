@@ -24,11 +24,11 @@ struct ofdm_ctx {
     float2 *d_tw = nullptr;       // exp(-2 pi i m / N)
     float2 *d_inv_trn = nullptr;  // 1 / training[k]
     float2 *d_header = nullptr;   // 10 * S un-normalised header samples
-    double *d_atan_tab = nullptr; // 32 x (cos, sin)(k pi / 16): the fused receive kernel's f64 atan2 (kernels_sync.hip)
     float header_max = 0.f;
     ofdm::Tuning tune;                  // ofdm_set_tuning: per-context A/B switches and grid shapes (no environment variable is read)
     ofdm::Trace trace;                  // ofdm_last_dispatch: the kernels the last entry point launched
     ofdm::ScStats sc_stats;             // list counters of the last Schmidl-Cox search (ofdm_get_tuning "stat_sc_*")
+    int32_t *d_stats = nullptr;         // [2] their home on the device (owned by the context)
     // workspaces (grown on demand, never inside a captured region)
     Workspace ws[10];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -78,4 +78,9 @@ __attribute__((visibility("hidden"))) void ofdm_host_pipe_destroy(ofdm_ctx *c); 
 // Schmidl-Cox over a batch (the dispatcher behind ofdm_sc_correlate_batch and step 1 of ofdm_rx_decode_batch; ofdm_abi.hip)
 __attribute__((visibility("hidden"))) int ofdm_abi_sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len, int64_t n_lags,
                     int32_t *d_hat, double *f_delta, float *metric);
+// ofdm_rx_decode_batch for ONE capture whose timing is already known (peak lag d_hat, arg P / L and metric at it): steps 2-5 of the
+// chain without its own search (ofdm_rx_decode_long with lag_lo > 0: the search must not look at lags in front of lag_lo)
+__attribute__((visibility("hidden"))) int ofdm_abi_rx_decode_known(ofdm_ctx *c, const ofdm_fc32 *in, int64_t frame_len, int32_t d_hat, double f_delta, float metric,
+                    int32_t max_symbols, uint8_t *out, int64_t out_stride, int32_t *out_len, int32_t *status, int32_t *offset, double *f_delta_out,
+                    float *metric_out);
 }

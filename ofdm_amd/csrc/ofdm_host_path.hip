@@ -68,14 +68,21 @@ int pipe_get(ofdm_ctx *c, HostPipe **out) {
     if (c->pipe) { *out = c->pipe; return OFDM_OK; }
     HostPipe *hp = new (std::nothrow) HostPipe();
     if (!hp) return OFDM_ERR_NOMEM;
-    c->pipe = hp; // from here on ofdm_destroy cleans up whatever was created
-    HIP_TRY(c, hipStreamCreateWithFlags(&hp->s_in, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&hp->s_out, hipStreamNonBlocking));
-    for (int s = 0; s < HostPipe::kSlots; s++) {
-        HIP_TRY(c, hipEventCreateWithFlags(&hp->in_done[s], hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&hp->k_done[s], hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&hp->out_done[s], hipEventDisableTiming));
-    }
+    // the pipe is published only when every stream and event exists: a failed creation must not leave a half-built pipe that later
+    // host calls would pick up with null streams; ofdm_host_pipe_destroy tolerates the partial one
+    auto build = [&]() -> int {
+        HIP_TRY(c, hipStreamCreateWithFlags(&hp->s_in, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamCreateWithFlags(&hp->s_out, hipStreamNonBlocking));
+        for (int s = 0; s < HostPipe::kSlots; s++) {
+            HIP_TRY(c, hipEventCreateWithFlags(&hp->in_done[s], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&hp->k_done[s], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&hp->out_done[s], hipEventDisableTiming));
+        }
+        return OFDM_OK;
+    };
+    const int rc = build();
+    c->pipe = hp;
+    if (rc) { ofdm_host_pipe_destroy(c); return rc; } // frees what was created and clears c->pipe
     *out = hp;
     return OFDM_OK;
 }
@@ -402,6 +409,8 @@ int decode_long_dev(ofdm_ctx *c, const float2 *in, int64_t n, int64_t lag_lo, in
     if (rc) return rc;
     int64_t start = 0, sub_lags = 0;
     LongGeom g;
+    bool have_sync = false;          // lag_lo > 0: the detection comes from the slice search below, not from the chain's own search
+    int64_t k_d = -1; double k_fd = 0.0; float k_m = 0.f;
     const bool whole = lag_lo == 0 && (lag_hi <= 0 || lag_hi >= n - (int64_t)(c->prm.sync_window_reps + 1) * c->S() + 1);
     const bool one_frame = whole && d_known < 0 && (!long_geometry(c, n, 0, 0, 0, g) || g.n_full == 0);
     if (c->prm.sync_mode == OFDM_SYNC_SCHMIDL_COX && !one_frame) { // (a capture no longer than one slice is one frame of the batch path)
@@ -412,6 +421,15 @@ int decode_long_dev(ofdm_ctx *c, const float2 *in, int64_t n, int64_t lag_lo, in
         // pass 2 (the chain's own search redoes that work on a few hundred samples anyway).
         const int L = c->S(), W = c->prm.sync_window_reps * L;
         int64_t d_lo = d_known, d_hi = d_known; // bracket of the first crossing: d1 in [d_lo - W, d_hi]
+        if (d_known < 0 && lag_lo > 0) {
+            // A partial lag range: the frame's trimmed start (peak - L - backoff) may lie in FRONT of lag_lo, so a sub-capture that holds the
+            // whole frame also holds lags the search must not see (the tail or plateau of an earlier packet would win: ADVICE r4).  The
+            // slice search is exact about "first crossing in [lag_lo, lag_hi)" (both passes); the chain then runs with that timing.
+            if ((rc = sc_long(c, in, n, lag_lo, lag_hi, 0, &k_d, &k_fd, &k_m))) return rc;
+            if (k_d < 0) return OFDM_OK;
+            have_sync = true;
+            start = std::max<int64_t>(k_d - L - c->prm.sync_backoff, 0) & ~(int64_t)1;
+        } else {
         if (d_known < 0) {
             if (!long_geometry(c, n, lag_lo, lag_hi, 0, g)) return OFDM_OK;
             LongHit hit;
@@ -422,11 +440,17 @@ int decode_long_dev(ofdm_ctx *c, const float2 *in, int64_t n, int64_t lag_lo, in
         const int64_t back = (int64_t)W + L + c->prm.sync_backoff;
         start = std::max<int64_t>(d_lo - back, 0) & ~(int64_t)1; // even: the sub-capture stays 16-byte aligned for the LDS-DMA kernels
         sub_lags = d_hi - start + W + 2;                           // covers d1 + W; the search clips it to the capture's own last lag
+        }
     } else if (c->prm.sync_mode != OFDM_SYNC_SCHMIDL_COX && !whole) {
         return OFDM_ERR_UNSUPPORTED; // the reference's detector is an argmax over the whole capture (src/receiver.rs:20-25)
     }
     if ((rc = dev_grow(c, hp, hp->d_scal, 64))) return rc;
     char *sc = static_cast<char *>(hp->d_scal.p); // f_delta f64 | len | status | offset i32 | metric f32
+    if (have_sync)
+        rc = ofdm_abi_rx_decode_known(c, reinterpret_cast<const ofdm_fc32 *>(in + start), n - start, (int32_t)(k_d - start), k_fd, k_m, max_symbols,
+                                      out_dev, out_cap, reinterpret_cast<int32_t *>(sc + 8), reinterpret_cast<int32_t *>(sc + 12),
+                                      reinterpret_cast<int32_t *>(sc + 16), reinterpret_cast<double *>(sc), reinterpret_cast<float *>(sc + 20));
+    else
     rc = ofdm_rx_decode_batch(c, reinterpret_cast<const ofdm_fc32 *>(in + start), 1, n - start, n - start, sub_lags, max_symbols, out_dev,
                               out_cap, reinterpret_cast<int32_t *>(sc + 8), reinterpret_cast<int32_t *>(sc + 12),
                               reinterpret_cast<int32_t *>(sc + 16), reinterpret_cast<double *>(sc), reinterpret_cast<float *>(sc + 20));
@@ -575,37 +599,44 @@ int ofdm_rx_decode_long_host(ofdm_ctx *c, const ofdm_fc32 *in_host, int64_t n_sa
     HostPipe *hp;
     int rc = pipe_get(c, &hp);
     if (rc) return rc;
-    const size_t bytes = (size_t)n_samples * sizeof(ofdm_fc32);
-    if ((rc = dev_grow(c, hp, hp->d_long, bytes + 64))) return rc;
-    if ((rc = dev_grow(c, hp, hp->d_out[0], (size_t)std::max<int64_t>(out_cap, 4) + 64))) return rc;
-    // upload: in place from pinned memory, else in 8 MB pieces through two pinned bounce slots (the copy of piece k + 1 overlaps
-    // the DMA of piece k)
-    if (host_pinned(in_host, bytes)) {
-        HIP_TRY(c, hipMemcpyAsync(hp->d_long.p, in_host, bytes, hipMemcpyHostToDevice, hp->s_in));
-    } else {
-        const size_t piece = (size_t)8 << 20;
-        for (int s = 0; s < 2; s++)
-            if ((rc = pin_grow(c, hp, hp->h_in[s], std::min(piece, bytes)))) return rc;
-        int k = 0;
-        for (size_t off = 0; off < bytes; off += piece, k++) {
-            const int s = k & 1;
-            const size_t nb = std::min(piece, bytes - off);
-            if (k >= 2) HIP_TRY(c, hipEventSynchronize(hp->in_done[s]));
-            std::memcpy(hp->h_in[s].p, reinterpret_cast<const char *>(in_host) + off, nb);
-            HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(hp->d_long.p) + off, hp->h_in[s].p, nb, hipMemcpyHostToDevice, hp->s_in));
-            HIP_TRY(c, hipEventRecord(hp->in_done[s], hp->s_in));
+    // Once the upload has started, DMA reads the caller's buffer (and later writes out_host): every failure below waits for all of
+    // it before the error goes back, as run_pipe does
+    auto work = [&]() -> int {
+        const size_t bytes = (size_t)n_samples * sizeof(ofdm_fc32);
+        if ((rc = dev_grow(c, hp, hp->d_long, bytes + 64))) return rc;
+        if ((rc = dev_grow(c, hp, hp->d_out[0], (size_t)std::max<int64_t>(out_cap, 4) + 64))) return rc;
+        // upload: in place from pinned memory, else in 8 MB pieces through two pinned bounce slots (the copy of piece k + 1 overlaps
+        // the DMA of piece k)
+        if (host_pinned(in_host, bytes)) {
+            HIP_TRY(c, hipMemcpyAsync(hp->d_long.p, in_host, bytes, hipMemcpyHostToDevice, hp->s_in));
+        } else {
+            const size_t piece = (size_t)8 << 20;
+            for (int s = 0; s < 2; s++)
+                if ((rc = pin_grow(c, hp, hp->h_in[s], std::min(piece, bytes)))) return rc;
+            int k = 0;
+            for (size_t off = 0; off < bytes; off += piece, k++) {
+                const int s = k & 1;
+                const size_t nb = std::min(piece, bytes - off);
+                if (k >= 2) HIP_TRY(c, hipEventSynchronize(hp->in_done[s]));
+                std::memcpy(hp->h_in[s].p, reinterpret_cast<const char *>(in_host) + off, nb);
+                HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(hp->d_long.p) + off, hp->h_in[s].p, nb, hipMemcpyHostToDevice, hp->s_in));
+                HIP_TRY(c, hipEventRecord(hp->in_done[s], hp->s_in));
+            }
         }
-    }
-    HIP_TRY(c, hipEventRecord(hp->in_done[2], hp->s_in));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, hp->in_done[2], 0));
-    rc = decode_long_dev(c, static_cast<const float2 *>(hp->d_long.p), n_samples, 0, 0, -1, max_symbols, static_cast<uint8_t *>(hp->d_out[0].p),
-                         out_cap, out_len, status, offset, f_delta, metric);
-    if (rc) { sync_all(c, hp); return rc; }
-    if (*status == OFDM_FRAME_OK && *out_len > 0) {
-        HIP_TRY(c, hipMemcpyAsync(out_host, hp->d_out[0].p, (size_t)*out_len, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    return OFDM_OK;
+        HIP_TRY(c, hipEventRecord(hp->in_done[2], hp->s_in));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, hp->in_done[2], 0));
+        rc = decode_long_dev(c, static_cast<const float2 *>(hp->d_long.p), n_samples, 0, 0, -1, max_symbols, static_cast<uint8_t *>(hp->d_out[0].p),
+                             out_cap, out_len, status, offset, f_delta, metric);
+        if (rc) return rc;
+        if (*status == OFDM_FRAME_OK && *out_len > 0) {
+            HIP_TRY(c, hipMemcpyAsync(out_host, hp->d_out[0].p, (size_t)*out_len, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        return OFDM_OK;
+    };
+    rc = work();
+    if (rc) sync_all(c, hp);
+    return rc;
 }
 
 } // extern "C"

@@ -33,6 +33,26 @@ def test_header_and_loader_agree(lib):
         assert hasattr(lib, n), f"libofdm_hip.so does not export {n}"
 
 
+def test_public_header_lists_only_the_keys_a_host_needs():
+    """the drop-in header documents at most 8 tuning keys; the laboratory switches (A/B between kernel variants,
+    profiling exits) are listed in the private ofdm_amd/csrc/ofdm_hip_tuning.h, which is what the library's key table is built from."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "ofdm_hip.h")).read()
+    a = hdr.index("/* Per-context knobs and counters.")
+    doc = hdr[a:hdr.index("int ofdm_set_tuning(", a)]
+    public = set(re.findall(r'"([a-z0-9_]+)"', doc))
+    assert public == {"grid_cap", "profile_build", "stat_sc_slow_frames", "stat_sc_redo_frames"}, public
+    priv = open(os.path.join(ROOT, "ofdm_amd", "csrc", "ofdm_hip_tuning.h")).read()
+    keys = re.findall(r'^OFDM_TUNE_KEY\("([a-z0-9_]+)"', priv, re.M)
+    assert len(keys) >= 20 and not (set(keys) & public)
+    comment = priv[: priv.index("#ifndef OFDM_TUNE_KEY")]
+    for k in keys:                      # every laboratory key is described where it is declared ...
+        assert k in comment, k
+        assert ('"' + k + '"') not in hdr, k   # ... and nowhere in the public header
+    abi = open(os.path.join(ROOT, "ofdm_amd", "csrc", "ofdm_abi.hip")).read()
+    assert '#include "ofdm_hip_tuning.h"' in abi
+
+
 def test_no_oracle_or_torch_in_the_boundary(lib):
     # the library is self-contained: it neither links the oracle nor exposes C++/torch types
     import subprocess

@@ -104,6 +104,40 @@ def test_decode_long_two_million_samples(api, orc):
     _same_decode(ctx.decode_long_host(pin, D), want, "host pinned")
 
 
+def test_decode_long_from_a_lag_in_front_of_the_second_packet(api, orc):
+    """ofdm_rx_decode_long(lag_lo = end of packet 1) on a two-packet capture.  The second frame's trimmed start and the
+    sub-capture the chain used to search both lie in front of lag_lo, where packet 1's tail still crosses the threshold: the answer must
+    be the one of decode on the capture from lag_lo on (re-based), not packet 1's tail.  lag_lo swept over the tail of packet 1, odd
+    and even, and over a point inside packet 2's plateau rise."""
+    rng = np.random.default_rng(417)
+    n, D = 40_000, 16
+    st1, st2 = 3000, 3000 + 2080 + 64 + 170           # packet 2 starts 170 samples after packet 1's channel tail
+    cap, pays = _capture(orc, rng, n, [st1, st2])
+    ctx = api.Context(n_fft=64, modulation=api.QAM64, guard_bands=True)
+    x = ctx.to_device(cap)
+    whole = orc.decode_sc(wide(cap), True, orc.QAM64, 64, max_symbols=D)
+    assert whole["status"] == 0 and bytes(whole["bytes"]) == pays[0]
+    d1 = orc.sc_sync(wide(cap), 80, 3, 0, 0.5)[0]
+    seen_second = 0
+    for lag_lo in (d1 + 1, d1 + 200, st1 + 2080 - 150, st1 + 2080 - 41, st1 + 2080 + 30, st2 - 75, st2 + 21):
+        tail = wide(cap[lag_lo:])
+        wd, _, wm, wfd = orc.sc_sync(tail, 80, 3, 0, 0.5)
+        assert wd >= 0
+        d, fd, m = ctx.sc_correlate_long(x, lag_lo=lag_lo)
+        assert d == lag_lo + wd and abs(fd - wfd) <= 1e-9, (lag_lo, d, lag_lo + wd)
+        got = ctx.decode_long(x, D, lag_lo=lag_lo)
+        # the oracle on the capture from lag_lo on decides WHICH crossing and its CFO; the frame it belongs to starts L + backoff samples
+        # in front of the peak -- possibly in front of lag_lo --, so the receive chain is the oracle's decode_given on the whole capture
+        off = max(lag_lo + wd - 80 - 4, 0)
+        want = orc.decode_given(wide(cap), off, wfd, True, orc.QAM64, 64, max_symbols=D)
+        assert got["status"] == want["status"], (lag_lo, got["status"], want["status"])
+        if want["status"] == 0:
+            assert got["offset"] == off and abs(got["f_delta"] - wfd) <= 1e-9, (lag_lo, got["offset"], off)
+            assert bytes(got["bytes"][: got["len"]].cpu().numpy()) == want["bytes"], lag_lo
+            seen_second += want["bytes"] == pays[1]
+    assert seen_second >= 3
+
+
 @pytest.mark.parametrize("n_fft,reps", [(64, 3), (64, 1), (256, 3), (1024, 2), (4096, 3)])
 def test_sc_correlate_long_slices_and_lag_ranges(api, orc, n_fft, reps):
     """The slice batch against one search of the whole capture for every period family (L = 80: k_sc_cf tiles; L >= 160:
@@ -217,6 +251,12 @@ def test_host_pipelines_equal_the_device_entry_points(api, orc, pinned):
         out = alloc(want_tx.shape, np.complex64)
         got = ctx.encode_host(pay, lens=lens, chunk_frames=chunk, out=out)
         assert np.array_equal(got.view(np.uint32), want_tx.view(np.uint32)), ("encode", chunk)
+    over = lens.copy(); over[1] = nbytes + 100; over[4] = 2 ** 30            # lengths above payload_bytes are clamped, on both sides alike
+    want_over = ctx.encode_batch(torch.from_numpy(np.ascontiguousarray(pay)).to(ctx.device), lens=torch.from_numpy(over)).cpu().numpy()
+    clamped = over.copy(); clamped[[1, 4]] = nbytes
+    want_clamped = ctx.encode_batch(torch.from_numpy(np.ascontiguousarray(pay)).to(ctx.device), lens=torch.from_numpy(clamped)).cpu().numpy()
+    got_over = ctx.encode_host(pay, lens=over, chunk_frames=9)
+    assert np.array_equal(want_over.view(np.uint32), want_clamped.view(np.uint32)) and np.array_equal(got_over.view(np.uint32), want_clamped.view(np.uint32))
     wide_out = np.zeros((nfr, want_tx.shape[1] + 7), np.complex64)           # a strided destination takes the scatter path
     ctx.encode_host(pay, lens=lens, chunk_frames=7, out=wide_out)
     assert np.array_equal(wide_out[:, : want_tx.shape[1]].view(np.uint32), want_tx.view(np.uint32))

@@ -873,16 +873,15 @@ def test_rx_decode_truncated_and_limited(api, orc, n, mod, guard):
 
 @pytest.mark.parametrize("mod,guard,ecc,cfo_mode", [(6, True, 0, 1), (6, True, 1, 1), (2, False, 0, 2), (4, True, 0, 0),
                                                      (8, False, 1, 1), (1, False, 0, 1), (8, True, 0, 2)])
-def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod, guard, ecc, cfo_mode):
-    """The one-pass receive kernel (k_sc_cf<..., BPS>: timing + CFO + channel estimate + demod + finish from the frame's
-    LDS image) against (a) the staged chain (k_sc_cf + k_sc_post + k_rx_prepare + k_rxframe64 [+ k_rx_finish]; switched in
-    ofdm_params.rx_path = OFDM_RX_STAGED; the one-pass kernel is OFDM_RX_ONE_PASS) -- every output identical except the CFO (two f64 atan2 evaluations: <= 1e-13) and decisions
-    the CFO's last bits can move -- and (b) the oracle, on a batch that mixes clean frames, noise-only slots (NOSYNC),
-    captures cut inside the header (SHORT) or inside a data symbol (pad_chunk), and a limited symbol count.
-    src/receiver.rs:9-96."""
+def test_rx_decode_chain_with_both_detectors_and_oracle(api, orc, mod, guard, ecc, cfo_mode):
+    """The N = 64 receive chain (k_sc80 / k_sc_cf + k_sc_post + k_rx_prepare + k_rxframe64 [+ k_rx_finish]) with either timing detector
+    -- every output identical except the CFO (sums that differ in their last bits: <= 1e-13) and decisions the CFO's last bits can
+    move -- and against the oracle, on a batch that mixes clean frames, noise-only slots (NOSYNC), captures cut inside the header
+    (SHORT) or inside a data symbol (pad_chunk), and a limited symbol count.  src/receiver.rs:9-96.  (Rounds 2-4 ran a one-pass
+    receive kernel through this test; it never beat the staged chain and was removed in round 5.)"""
     rng = np.random.default_rng(900 + mod + ecc + cfo_mode)
     ctx = api.Context(n_fft=64, modulation=mod, guard_bands=guard, ecc=ecc, cfo_mode=cfo_mode, rx_path=api.RX_STAGED)
-    ctx1 = api.Context(n_fft=64, modulation=mod, guard_bands=guard, ecc=ecc, cfo_mode=cfo_mode, rx_path=api.RX_ONE_PASS)
+    ctx1 = api.Context(n_fft=64, modulation=mod, guard_bands=guard, ecc=ecc, cfo_mode=cfo_mode, tuning={"no_sc80": 1})
     nbytes = 200 if mod > 1 else 100
     D = ctx.data_symbols(nbytes)
     flen = ctx.frame_samples(nbytes)
@@ -906,7 +905,7 @@ def test_rx_decode_one_pass_kernel_equals_staged_chain_and_oracle(api, orc, mod,
     for label, flen_used in frame_lens.items():
         for max_sym in (D, max(1, D - 3)):
             one = {k: host(v) for k, v in ctx1.decode_batch(dev(ctx1, caps), max_symbols=max_sym, frame_len=flen_used).items()}
-            assert ctx1.last_dispatch().startswith("k_sc_cf<rx>+k_sc_tile<list>+k_rx_prepare<list>+k_rxframe64<list>"), ctx1.last_dispatch()
+            assert ctx1.last_dispatch().startswith("k_sc_cf<") and "+k_rx_prepare+k_rxframe64" in ctx1.last_dispatch(), ctx1.last_dispatch()
             two = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=max_sym, frame_len=flen_used).items()}
             d2 = ctx.last_dispatch()
             assert d2.startswith("k_sc80+") and "<rx>" not in d2 and "+k_rx_prepare+k_rxframe64" in d2, d2
@@ -1551,6 +1550,27 @@ def test_outer_rs_over_the_link(api, orc):
     assert plain is not None and plain[:500] == text == orc.decipher_transmission_bytes(got)[:500]
     cap[start:start + 80 * 8] = 0  # 48 bytes gone: beyond 16 per block -> None, like the reference
     assert api.decipher_transmission_bytes(api.decode(cap, True, api.BPSK)) is None
+
+
+def test_lab3c_image_fixture_over_the_link_on_gpu(api, orc):
+    """examples/lab3c_image.rs with the reference's own payload (support/dancing.bytes -> tests/golden/dancing.bytes, data): bytes ->
+    create_transmission_bytes -> encode!(guard_bands) -> [fc32 file format] -> channel -> decode!(guard_bands) ->
+    decipher_transmission_bytes == the image, on the GPU back-end, sample-for-sample and byte-for-byte against the oracle."""
+    import os
+    img = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dancing.bytes"), "rb").read()
+    assert len(img) == 576
+    coded = api.create_transmission_bytes(img)
+    assert coded == orc.create_transmission_bytes(img) and len(coded) == 765
+    tx = api.encode(coded, True)                                   # modulation defaults to BPSK (transmitter.rs:16-17)
+    assert tx.size == 800 + 80 * 131 and rel_err(tx, orc.encode(coded, True, orc.BPSK)) <= TOL
+    wire = api.sig_to_bytes(tx)                                    # utils::sig_to_bytes: what --transmit writes (fc32)
+    rx, _ = orc.channel(api.bytes_to_sig(wire), 30.0, True, seed=24)
+    for sync in ({}, {"sync_mode": api.SYNC_REFERENCE}):           # Schmidl-Cox timing and the reference's xcorr_fft timing
+        got = api.decode(rx, True, cfo_mode=api.CFO_ABS, **sync)
+        assert got == coded
+        plain = api.decipher_transmission_bytes(got)
+        assert plain is not None and plain[:576] == img == orc.decipher_transmission_bytes(got)[:576]
+    assert orc.analysis(coded, got) == (0, 0, 0.0)
 
 
 @pytest.mark.parametrize("n,mod,guard", [(64, 6, True), (64, 1, False), (256, 4, True), (1024, 6, True), (4096, 8, True)])

@@ -279,6 +279,36 @@ def test_loopback_lab3(orc, timing_error):
     assert orc.analysis(data, res["bytes"])[0] == 0
 
 
+# ---- examples/lab3c_image.rs: the reference's one data fixture (support/dancing.bytes, a 24 x 24 palette frame: DATA, copied to
+#      tests/golden/dancing.bytes) -> create_transmission_bytes -> encode!(guard_bands) [BPSK] -> channel -> decode! ->
+#      decipher_transmission_bytes (src/utils.rs:97-180)
+def dancing_bytes():
+    import os
+    return open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dancing.bytes"), "rb").read()
+
+
+def test_lab3c_image_fixture_over_the_link(orc):
+    img = dancing_bytes()
+    assert len(img) == 576 == 24 * 24                       # examples/lab3c_image.rs:70 `let dims = (24, 24)`
+    coded = orc.create_transmission_bytes(img)
+    assert len(coded) == 3 * 255                            # 576 = 223 + 223 + 130 -> three RS(255,223) blocks (zero-filled tail)
+    tx = orc.encode(coded, True, orc.BPSK)                  # ofdm::encode!(data, guard_bands): modulation defaults to BPSK
+    assert tx.size == 800 + 80 * 131                        # 16 + 765 bytes at 48 bits per symbol
+    rx, _ = orc.channel(tx, 30.0, True, seed=24)
+    for res in (orc.decode_ref(rx, True, orc.BPSK), orc.decode_sc(rx, True, orc.BPSK, cfo_abs=True)):
+        assert res["status"] == 0 and bytes(res["bytes"]) == coded
+        plain = orc.decipher_transmission_bytes(bytes(res["bytes"]))
+        # (765 = 3 x 255 exactly: the reference's loop then decodes one more, all-zero block at end of input, utils.rs:172-176)
+        assert plain is not None and len(plain) == 4 * 223 and plain[:576] == img and not any(plain[576:])
+    # sixteen byte errors in one block are repaired, seventeen are not (t = 16)
+    bad = bytearray(coded)
+    for i in range(16):
+        bad[255 + 7 * i] ^= 0x5A
+    assert orc.decipher_transmission_bytes(bytes(bad))[:576] == img
+    bad[255 + 7 * 16] ^= 0x5A
+    assert orc.decipher_transmission_bytes(bytes(bad)) is None
+
+
 def test_decode_too_short(orc):
     res = orc.decode_ref(np.concatenate([np.zeros(5) + 0j, orc.locking_signal(80), np.zeros(300) + 0j]), False, orc.BPSK)
     assert res["status"] == -1  # "Input not long enough, bailing early" (receiver.rs:27-29)

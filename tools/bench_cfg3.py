@@ -2,7 +2,6 @@
 integer delay, a random signed CFO and 30 dB noise; full RX chain (timing -> CFO -> channel estimate -> FFT -> equalise ->
 pilot phase -> demap -> length header) on one GPU.  Reports
   * the chain searching EVERY lag of every slot (the headline of this block) and bounded to the slot's 256 possible lags,
-    staged (two HBM passes) and through the one-pass kernel (ofdm_params.rx_path = OFDM_RX_ONE_PASS),
   * Schmidl-Cox alone against the HBM roofline (north-star target >= 40 %): the kernel that computes every lag, and the
     product's two-launch search (first lags decide, the rest of the slot is read only for frames they do not determine),
   * the TX side (encode) for the same payloads,
@@ -127,7 +126,7 @@ def _roof(bytes_, ms, **extra):
 def _traffic(kernels):
     """HBM bytes per frame of the named kernels from the newest committed PMC pass (tools/pmc_traffic.py), or None."""
     import json
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{rnd}_pmc_traffic.json")
         try:
             pm = json.load(open(path))["per_kernel"]
@@ -140,15 +139,14 @@ def _traffic(kernels):
     return None, None
 
 
-def chain_block(api, torch, ctx, x, payload, n_frames, steps, grp, W_, name_suffix="", one_pass=True, span=SPAN, traffic_keys=None):
-    """The full RX chain over one data set: every lag, bounded, one-pass kernel; Schmidl-Cox alone (every lag computed; the product's
+def chain_block(api, torch, ctx, x, payload, n_frames, steps, grp, W_, name_suffix="", bounded=True, span=SPAN, traffic_keys=None):
+    """The full RX chain over one data set: every lag, bounded; Schmidl-Cox alone (every lag computed; the product's
     two-launch early-exit search).  Every early-exit block carries TWO figures: `capture_throughput` (slot bytes / time: what a user
     sees, NOT a roofline -- an early exit skips bytes) and `roofline` (bytes the decision REQUIRES / time)."""
     out = {}
     D = ctx.data_symbols(NBYTES)
     L, Wn = ctx.S, ctx.params.sync_window_reps * ctx.S
     slot_bytes = n_frames * (span * 8 + NBYTES)
-    ctx.set_tuning("one_pass_rx", 0)
     d_all, _, _ = ctx.sc_correlate(x)
     sync_req = required_sync_bytes(torch, d_all, span, Wn, L)
     found = int((d_all >= 0).sum())
@@ -160,13 +158,10 @@ def chain_block(api, torch, ctx, x, payload, n_frames, steps, grp, W_, name_suff
                                            "threshold-then-peak detector must read; chain: + (5 + D) N useful samples and the payload of every "
                                            "frame found"}
 
-    def leg(name, lags, one):
-        ctx.set_tuning("one_pass_rx", int(one))
-        try:
-            ms, per_rank, r = _timed(ctx, torch, lambda: ctx.decode_batch(x, max_symbols=D, n_lags=lags), steps, grp)
-        finally:
-            ctx.set_tuning("one_pass_rx", 0)
-        early_exit = not one and lags == 0          # the two-launch search stops reading a slot once its decision is determined
+    def leg(name, lags):
+        ms, per_rank, r = _timed(ctx, torch, lambda: ctx.decode_batch(x, max_symbols=D, n_lags=lags), steps, grp)
+        one = False
+        early_exit = lags == 0                      # the streaming detector stops reading a slot once its decision is determined
         bytes_ = chain_req if early_exit else slot_bytes
         tr, src = _traffic(traffic_keys) if (traffic_keys and early_exit) else (None, None)
         out[name + name_suffix] = {
@@ -177,36 +172,37 @@ def chain_block(api, torch, ctx, x, payload, n_frames, steps, grp, W_, name_suff
             "roofline": _roof(bytes_, ms, per="GPU (slowest rank)", algorithmic_bytes_per_launch=bytes_,
                               bytes="required (see required_bytes)" if early_exit else "the whole slot once + payload",
                               traffic=None if tr is None else tr * n_frames, traffic_source=src,
-                              kernels="k_sc_cf<256,2,3,6,true> (one pass)" if one else
-                                      "k_sc_cf<128,2,4,0> over the first lags + k_sc_cf<256,2,4,0> over the frames they do not determine (bounded: "
-                                      "k_sc_cf<128,2,4,0> alone) + k_sc_post + k_sc_tile<list> + k_rx_prepare + k_rxframe64<6,true> (finish fused); see dispatch")}
+                              kernels="k_sc80<2> (every lag on f64 prefix differences; stops when the peak window has closed) + k_sc_post + "
+                                      "k_sc_tile<list> + k_rx_prepare + k_rxframe64<6,true> (finish fused); see dispatch")}
         return r
 
-    full = leg("full_chain_all_lags", 0, False)
+    full = leg("full_chain_all_lags", 0)
     res = {"full": full}
-    if one_pass:
-        res["bounded"] = leg("full_chain_bounded_256_lags", SYNC_LAGS, False)
-        res["one"] = leg("full_chain_all_lags_one_pass_kernel", 0, True)
-    # --- Schmidl-Cox alone over every lag of every slot: (a) the kernel that COMPUTES every lag (one launch, tuning sc_first_lags = 0:
-    #     the north-star kernel against the HBM roofline, bytes = the whole slot, which it does read), (b) the product path: the first
-    #     576 lags decide every frame whose crossing and peak window lie among them, the rest take the whole search (same results)
+    if bounded:
+        res["bounded"] = leg("full_chain_bounded_256_lags", SYNC_LAGS)
+    # --- Schmidl-Cox alone: (a) the product's search, k_sc80 -- every lag it evaluates is exact, and it stops reading a slot when the
+    #     peak window has closed: capture throughput + roofline on the bytes the decision requires; (b) the round-4 f32 filter kernel that
+    #     computes EVERY lag of every slot (tuning no_sc80 = 1, sc_first_lags = 0): the whole slot is read, so slot bytes are its roofline
     sc_slot = n_frames * (span * 8 + 16)
     first = ctx.get_tuning("sc_first_lags")
-    for name, fl in (("schmidl_cox", 0), ("schmidl_cox_two_launches", first)):
-        ctx.set_tuning("sc_first_lags", fl)
+    for name, keys in (("schmidl_cox", {}), ("schmidl_cox_f32_filter_every_lag", {"no_sc80": 1, "sc_first_lags": 0})):
+        for k, v in keys.items():
+            ctx.set_tuning(k, v)
         try:
             sms, _, _ = _timed(ctx, torch, lambda: ctx.sc_correlate(x), steps, grp)
             disp = ctx.last_dispatch()
         finally:
             ctx.set_tuning("sc_first_lags", first)
-        bytes_ = sc_slot if fl == 0 else sync_req + 16 * n_frames
+            ctx.set_tuning("no_sc80", 0)
+        every = bool(keys)
+        bytes_ = sc_slot if every else sync_req + 16 * n_frames
         out[name + name_suffix] = {
-            "kernel": disp + (f" (all {span - Wn - L + 1} lags of every {span}-sample slot computed)" if fl == 0 else
-                              f" (first {fl} lags, then the whole search for the frames they do not determine)"),
+            "kernel": disp + (f" (all {span - Wn - L + 1} lags of every {span}-sample slot computed)" if every else
+                              " (every lag up to the end of the peak window, exactly; the rest of the slot is never fetched)"),
             "kernel_ms": sms, "msamples_per_s": W_ * n_frames * span / sms / 1e3,
             "capture_throughput": {"gb_per_s": sc_slot / (sms / 1e3) / 1e9, "of_hbm_peak": sc_slot / (sms / 1e3) / 1e9 / HBM_PEAK_GBS},
             "roofline": _roof(bytes_, sms, algorithmic_bytes_per_launch=bytes_,
-                              bytes="the whole slot (every lag is computed)" if fl == 0 else "required (see required_bytes)")}
+                              bytes="the whole slot (every lag is computed)" if every else "required (see required_bytes)")}
     return out, res
 
 
@@ -224,9 +220,9 @@ def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
            "parity": "64-QAM and the Schmidl-Cox detector are north-star extensions the reference lacks (EXT-1, EXT-3): parity unpinned by "
                      "the reference, the oracle is the definition"}
     blocks, res = chain_block(api, torch, ctx, x, payload, n_frames, steps, grp, W,
-                              traffic_keys=("k_sc_cf_128_first_lags", "k_rxframe64"))
+                              traffic_keys=("k_sc80", "k_rxframe64"))
     out.update(blocks)
-    full, bounded, one = res["full"], res["bounded"], res["one"]
+    full, bounded = res["full"], res["bounded"]
     nok, ber = _ber(torch, full, payload)  # this rank's frames (rank 0's in the report)
     out["frames_decoded"] = nok
     out["ber_decoded_frames_vs_tx_payload"] = ber
@@ -237,17 +233,19 @@ def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
         "frames_with_different_status": int((full["status"] != bounded["status"]).sum()),
         "note": "n_lags also clips the peak window [d1, d1 + W]: see DESIGN.md section 3 (EXT-3) and "
                 "tests/test_gpu_parity.py::test_bounded_search_clips_the_peak_window"}
-    out["one_pass_vs_staged"] = {
-        "status_offset_len_equal": bool(((one["status"] == full["status"]) & (one["offset"] == full["offset"])
-                                         & (one["len"] == full["len"])).all()),
-        "frames_with_different_bytes": int((one["bytes"][:, :NBYTES] != full["bytes"][:, :NBYTES]).any(dim=1).sum()),
-        "max_cfo_difference": float((one["f_delta"] - full["f_delta"]).abs().max())}
     if cpu and rank == 0:
         from tools import cpu_baseline as cb
         threads = cb.host_threads()
         out["cpu_baseline"] = cpu_leg(x, payload, full, D, min(n_frames, 65536, 1024 * threads), threads)
         out["speedup_vs_cpu"] = out["full_chain_all_lags"]["msamples_per_s"] / out["cpu_baseline"]["value"]
-    del full, bounded, one, res
+    del full, bounded, res
+    # --- slots without a packet: k_sc80 has to evaluate every lag and read every byte -- its rate against the slot roofline
+    nn = min(n_frames, 262144)
+    xn = torch.view_as_complex(torch.randn((nn, SPAN, 2), dtype=torch.float32, device=ctx.device) * 0.004)
+    nms, _, _ = _timed(ctx, torch, lambda: ctx.sc_correlate(xn), steps, grp)
+    out["schmidl_cox_noise_only_slots"] = {"kernel": ctx.last_dispatch() + " (no packet: every lag of every slot evaluated exactly, every byte read)",
+                                           "frames": nn, "kernel_ms": nms, "roofline": _roof(nn * (SPAN * 8 + 16), nms, bytes="the whole slot")}
+    del xn
     # --- TX side of the hot path: encode (modulate + encode_block + IFFT + CP + header + normalise) for the same payloads
     npay = min(n_frames, 262144)
     txo = ctx.encode_batch(payload[:npay])
@@ -261,7 +259,7 @@ def run(api, torch, n_frames, steps, device, cpu=True, grp=None):
     #     (half of the crossings beyond the first launch's reach) and 10 % of the slots without a packet
     late_delay = LATE_SPAN - 2080 - 63
     xl, pl = synth(api, torch, ctx, n_frames, span=LATE_SPAN, seed=31 + rank, max_delay=late_delay, noise_only=LATE_NOISE_ONLY)
-    lblocks, lres = chain_block(api, torch, ctx, xl, pl, n_frames, steps, grp, W, name_suffix="_late_packets", one_pass=False, span=LATE_SPAN)
+    lblocks, lres = chain_block(api, torch, ctx, xl, pl, n_frames, steps, grp, W, name_suffix="_late_packets", bounded=False, span=LATE_SPAN)
     nok_l, ber_l = _ber(torch, lres["full"], pl)
     late_cpu = None
     if cpu and rank == 0:  # the oracle on a sample of the late / empty slots: the placements round 3's f32 filter sent to the all-f64 kernel
