@@ -244,7 +244,7 @@ int ofdm_rx_demod_batch(ofdm_ctx *ctx, const ofdm_fc32 *in_dev, int64_t n_frames
 
 /* encode (src/transmitter.rs:11-58) for a batch: frame f = [lock][preamble x4][training x5][data symbols],
  * normalised per frame.  payload f = payload_dev[f*payload_stride .. + len_f), len_f = payload_len_dev[f] or
- * payload_bytes when NULL.  EVERY row, the last one included, must be READABLE for payload_bytes bytes whatever its len_f (the
+ * payload_bytes when NULL; a len_f outside [0, payload_bytes] is clamped to that range.  EVERY row, the last one included, must be READABLE for payload_bytes bytes whatever its len_f (the
  * kernels prefetch whole rows and mask afterwards): payload_stride >= payload_bytes (OFDM_ERR_INVALID otherwise when n_frames > 1),
  * and the buffer ends no earlier than the last row's payload_bytes.  Every frame is laid out for payload_bytes (D = ofdm_data_symbols(payload_bytes))
  * and written to out_dev[f*out_stride ..] (out_stride >= ofdm_frame_samples(payload_bytes)).

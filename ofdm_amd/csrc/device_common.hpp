@@ -315,6 +315,12 @@ __device__ __forceinline__ unsigned raw_bits(const uint8_t *__restrict__ bytes, 
     return ((lo | (hi << 8)) >> (bit & 7)) & ((1u << bps) - 1u);
 }
 
+// A payload row's own length: callers' values outside [0, payload_bytes] are clamped (a length above the row would read the next row --
+// or, behind the last row, unmapped memory -- and claim bytes the frame has no symbols for)
+__device__ __forceinline__ long long row_len(long long v, int payload_bytes) {
+    return v < 0 ? 0 : (v > payload_bytes ? (long long)payload_bytes : v);
+}
+
 // ---- Hamming(7,4): codeword bits [d0 d1 d2 d3 p0 p1 p2], LSB first
 __device__ __forceinline__ unsigned ham_enc(unsigned d) {
     unsigned d0 = d & 1u, d1 = (d >> 1) & 1u, d2 = (d >> 2) & 1u, d3 = (d >> 3) & 1u;

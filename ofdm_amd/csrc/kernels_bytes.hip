@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_ham_encode(const uint8_t *in, long long
     const long long total = n_frames * blocks_per_frame;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         long long f = i / blocks_per_frame, b = i - f * blocks_per_frame;
-        const long long len = in_len ? in_len[f] : n_bytes;
+        const long long len = in_len ? row_len(in_len[f], (int)n_bytes) : n_bytes;   // a row's own length, clamped to the row
         const uint8_t *src = in + f * in_stride;
         unsigned long long acc = 0;
 #pragma unroll

@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
     int cur = 0;
     if (f < p.n_frames) {
         issue(f, pre0, pre1, pre_len);
-        len = __builtin_amdgcn_readfirstlane(pre_len);
+        len = row_len(__builtin_amdgcn_readfirstlane(pre_len), p.payload_bytes);
         fill(sbw_all, f, pre0, pre1, len);
         issue(f + gridDim.x, pre0, pre1, pre_len);
     }
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256, 4) void k_txframe64(TxFrame64Params p) {
         if (kProfile && p.debug) t1 = (long long)__builtin_amdgcn_s_memtime();
         long long len_next = 0;
         if (f + gridDim.x < p.n_frames) { // workgroup-uniform
-            len_next = __builtin_amdgcn_readfirstlane(pre_len);
+            len_next = row_len(__builtin_amdgcn_readfirstlane(pre_len), p.payload_bytes);
             fill(sbw_all + (cur ^ 1) * sbw_dw, f + gridDim.x, pre0, pre1, len_next);
         }
         if (tid == 0) mxw[cur ^ 1] = 0u; // last read in the previous frame's store phase, which every thread left before this frame's first barrier
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(512, 4) void k_txframe4096(TxFrame4096Params p) {
 
     for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
         if (tid == 0) *fmax = 0u;
-        const long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+        const long long len = p.payload_len ? row_len(p.payload_len[f], p.payload_bytes) : p.payload_bytes;
         const uint8_t *pay = p.payload + f * p.payload_stride;
         cf *row = p.out + f * p.out_stride;
         for (int pass = 0; pass < 2; ++pass) {

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     auto build = [&](bool valid, long long f, int k, cf *v) {
         long long len = 0;
         if (valid) {
-            len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+            len = p.payload_len ? row_len(p.payload_len[f], p.payload_bytes) : p.payload_bytes;
             const uint8_t *pay = p.payload + f * p.payload_stride;
             const long long sb0 = (long long)k * sym_bytes;
             sbw[l] = 4 * l < sym_bytes ? dword(pay, len, sb0 + 4 * l) : 0u;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
         if (sg >= total) return;
         long long f; int k;
         split(sg, f, k);
-        long long len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+        long long len = p.payload_len ? row_len(p.payload_len[f], p.payload_bytes) : p.payload_bytes;
         if (tx_raw) { const long long left = p.tx_raw_total - f * p.payload_stride; len = left < 0 ? 0 : (left < len ? left : len); }
         const uint8_t *pay = p.payload + f * p.payload_stride;
         const long long sb0 = (long long)k * tx_sym_bytes;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(Plan<N>::WG) void k_sym(SymParams p) {
             const bool raw = p.tx_raw_total >= 0;
             long long len = 0, nsym = 0;
             if (valid) {
-                len = p.payload_len ? p.payload_len[f] : p.payload_bytes;
+                len = p.payload_len ? row_len(p.payload_len[f], p.payload_bytes) : p.payload_bytes;
                 if (raw) { // this symbol's share of the continuous byte stream (zeros once it runs dry, transmitter.rs:158-160)
                     const long long left = p.tx_raw_total - f * p.payload_stride;
                     len = left < 0 ? 0 : (left < len ? left : len);

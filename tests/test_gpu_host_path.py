@@ -134,7 +134,7 @@ def test_decode_long_from_a_lag_in_front_of_the_second_packet(api, orc):
         if want["status"] == 0:
             assert got["offset"] == off and abs(got["f_delta"] - wfd) <= 1e-9, (lag_lo, got["offset"], off)
             assert bytes(got["bytes"][: got["len"]].cpu().numpy()) == want["bytes"], lag_lo
-            seen_second += want["bytes"] == pays[1]
+            seen_second += sum(a != b for a, b in zip(want["bytes"], pays[1])) <= 4   # packet 2 (64-QAM at 30 dB: a byte or two may be wrong)
     assert seen_second >= 3
 
 
