@@ -8,7 +8,7 @@ import json, sys
 tsv, log, rnd = sys.argv[1:4]
 cnt, cmax = {}, {}
 for line in open(tsv):
-    name, ctr, calls, mean, mx = line.rstrip("\n").split("\t")
+    name, ctr, calls, mean, mx = line.rstrip("\n").split("\t")[:5]
     cnt[(name.replace("void ", ""), ctr)] = float(mean.split("=")[1])
     cmax[(name.replace("void ", ""), ctr)] = float(mx.split("=")[1])
 info = next(json.loads(l) for l in open(log) if l.startswith("{"))
