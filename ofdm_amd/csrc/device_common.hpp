@@ -213,12 +213,14 @@ __device__ __forceinline__ unsigned axis_code(unsigned l, int m) {
     return __brev(g) >> (32 - m);              // first stream bit at bit 0
 }
 // returns the bps-bit index: bit j = j-th bit of the point in stream order
+// clamp(f, 0, top) as ONE v_med3_f32 (v_max_f32 and v_min_f32 each cost what it costs: 4 cycles per wavefront on gfx950, twice a
+// v_add_f32 -- tools/ubench/valu_rate.hip); a NaN gives min3 of the operands = 0, as fminf(fmaxf(NaN, 0), top) did
+__device__ __forceinline__ float clamp0(float f, float top) { return __builtin_amdgcn_fmed3f(f, 0.0f, top); }
 __device__ __forceinline__ unsigned axis_bits(float x, int m) {
     const int M = 1 << m;
     // l = clamp(floor(x (M-1) / 2) + M/2, 0, M-1): one fma, clamp, truncating convert (the clamped value is non-negative, so
-    // truncation is the floor; NaN -> 0 because fmaxf returns the non-NaN operand)
-    float f = fmaf(x, 0.5f * (float)(M - 1), (float)(M / 2));
-    f = fminf(fmaxf(f, 0.0f), (float)(M - 1));
+    // truncation is the floor; NaN -> 0)
+    const float f = clamp0(fmaf(x, 0.5f * (float)(M - 1), (float)(M / 2)), (float)(M - 1));
     return axis_code((unsigned)f, m);
 }
 __device__ __forceinline__ unsigned demap_point(cf z, int bps) {
@@ -235,7 +237,7 @@ __device__ __forceinline__ unsigned demap_point(cf z, int bps) {
         // 256-QAM: both axes' levels side by side (Q below I), Gray-coded together (the mask keeps the shift inside each nibble),
         // and ONE 32-bit bit reversal turns the byte round: rev4(gray(l_I)) lands in the low nibble, rev4(gray(l_Q)) in the high
         // one -- 12 instead of 17 instructions per point against the two table look-ups of axis_bits (two 32-bit halves each)
-        const float fi = fminf(fmaxf(fmaf(z.x, 7.5f, 8.0f), 0.0f), 15.0f), fq = fminf(fmaxf(fmaf(z.y, 7.5f, 8.0f), 0.0f), 15.0f);
+        const float fi = clamp0(fmaf(z.x, 7.5f, 8.0f), 15.0f), fq = clamp0(fmaf(z.y, 7.5f, 8.0f), 15.0f);
         const unsigned x = (unsigned)fq | ((unsigned)fi << 4);
         const unsigned g = x ^ ((x >> 1) & 0x77u);
         return __brev(g) >> 24;
@@ -250,8 +252,8 @@ __device__ __forceinline__ unsigned demap_point_rot(cf z, cf rot, int bps) {
     const int m = bps >> 1, M = 1 << m;
     const float sc = 0.5f * (float)(M - 1), half = (float)(M / 2), top = (float)(M - 1);
     const float rx = rot.x * sc, ry = rot.y * sc;       // common to the eight points of a lane: computed once
-    const float fi = fminf(fmaxf(fmaf(z.x, rx, fmaf(-z.y, ry, half)), 0.0f), top);
-    const float fq = fminf(fmaxf(fmaf(z.x, ry, fmaf(z.y, rx, half)), 0.0f), top);
+    const float fi = clamp0(fmaf(z.x, rx, fmaf(-z.y, ry, half)), top);
+    const float fq = clamp0(fmaf(z.x, ry, fmaf(z.y, rx, half)), top);
     if (bps == 8) {
         const unsigned x = (unsigned)fq | ((unsigned)fi << 4);
         const unsigned g = x ^ ((x >> 1) & 0x77u);

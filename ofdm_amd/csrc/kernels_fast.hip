@@ -831,9 +831,13 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     cf *buf = slab_all + wave * SLAB + s * 72;
     const int wr = swz(8 * t);
 
-    cf w[7];                                      // W64^(r t)
-#pragma unroll
-    for (int r = 1; r < 8; ++r) w[r - 1] = p.tw[64 * r * t];
+    // W64^(r t), r = 1 .. 7, read from a 56-entry LDS table at use: as fourteen loop-invariant registers they pushed the kernel over its
+    // 128 VGPRs, and a spilled register comes back through scratch -- a VMEM load, in order behind the next symbol's prefetch, so that every
+    // reload waited for the prefetch (round-5 ISA scan: 3 to 10 spilled registers in every instantiation, each reloaded right after a barrier)
+    cf *wtab = reinterpret_cast<cf *>(reinterpret_cast<unsigned char *>(red) + 64 + 256);   // [8][7], behind the pilot sums and the frame-mode offset table
+    if (tid < 56) wtab[tid] = p.tw[64 * (tid % 7 + 1) * (tid / 7)];
+    __syncthreads();
+    const cf *w = wtab + 7 * t;
     cf z[8];                                      // W4096^(b c), c = t + 8 q
 #pragma unroll
     for (int q = 0; q < 8; ++q) z[q] = p.tw[col * (t + 8 * q)];
@@ -884,8 +888,26 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     // The image of symbol j is stored to HBM in iteration j + 1, behind that iteration's FIRST barrier (which is what makes the
     // image complete: no barrier of its own) and long before the next wait for prefetched samples: loads and stores share the
     // in-order VM counter, so stores issued just before a wait-for-loads would be waited for as well.
-    auto flush = [&](unsigned *dst) { // image -> global, and clear it for the next symbol (same thread, same dwords)
-        for (int i = tid; i < IMG_DW; i += 512) { dst[i] = img[i]; img[i] = 0u; }
+    // image -> global, and clear it for the next symbol (same thread, same dwords).  Straight-line code: written as a loop over the
+    // dwords, the compiler put s_waitcnt vmcnt(0) in front of it -- i.e. the whole workgroup waited here, once per symbol, for the NEXT
+    // symbol's samples, which had been requested a few hundred instructions earlier (round-5 ISA scan).  IMG_DW is a multiple of 4 and at
+    // most 1024: with 16-byte aligned rows one predicated 16-byte store per thread, else at most two dword stores.
+    // (Whole-byte / nibble fields are written with plain stores, every dword of the image by exactly one lane: nothing to clear there;
+    //  only the atomic-OR packing of 1-, 2- and 6-bit fields needs a zeroed image -- and a zero 4-vector was one more register than the
+    //  kernel has: it came back from scratch, a VMEM load the prefetch had to be waited for behind.)
+    const bool wide_out = ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)p.out_stride) & 15) == 0;   // (nbytes is a multiple of 16)
+    constexpr bool CLEAR = !(BPS == 8 || BPS == 4);
+    auto flush = [&](unsigned *dst) {
+        if (wide_out) {
+            if (tid < IMG_DW / 4) {
+                unsigned *i1 = img + 4 * tid;
+                reinterpret_cast<uint4 *>(dst)[tid] = *reinterpret_cast<const uint4 *>(i1);
+                if (CLEAR) { i1[0] = 0u; i1[1] = 0u; i1[2] = 0u; i1[3] = 0u; }
+            }
+        } else {
+            if (tid < IMG_DW) { dst[tid] = img[tid]; if (CLEAR) img[tid] = 0u; }
+            if (IMG_DW > 512 && tid + 512 < IMG_DW) { dst[tid + 512] = img[tid + 512]; if (CLEAR) img[tid + 512] = 0u; }
+        }
     };
     for (int i = tid; i < IMG_DW; i += 512) img[i] = 0u;
     cf pre[8];
@@ -1033,7 +1055,7 @@ hipError_t run_demod4096(const SymParams &sp, hipStream_t st, int num_cu) {
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.bps = sp.bps; p.guard = sp.guard;
     p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym_frame = sp.nsym_frame; p.frame_len = sp.frame_len;
     if (p.total <= 0) return hipSuccess;
-    const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64 + 256; // slabs, T, image, pilot sums + spare dword, frame-mode offset table
+    const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 64 + 256 + 448; // slabs, T, image, pilot sums + spare dword, frame-mode offset table, stage twiddles
     long long grid = (long long)num_cu * 2;
     { const long long cap = tuning_or_default(sp.tune).grid_cap; if (cap > 0 && cap < grid) grid = cap; } // test hook, as kernels_mid.hip
     if (grid > p.total) grid = p.total;

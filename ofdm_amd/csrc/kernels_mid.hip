@@ -178,9 +178,20 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
     cf *buf = slab_all + wave * M::SLAB + (lane >> 3) * 72;
     const int wr = swz(8 * t);
 
-    cf w[7];                                        // W64^(r t)
+    // W64^(r t), r = 1 .. 7: a 56-entry LDS table read at use instead of fourteen loop-invariant registers -- the instantiations that ran
+    // out of registers reloaded their spills from scratch, a VMEM load queued behind the next symbol's prefetch (round-5 ISA scan)
+    // (R >= 16 runs at three waves per SIMD and never spilled: there the registers stay -- the table's reads cost it 5 % when tried)
+    constexpr bool W_LDS = R < 16;
+    __shared__ cf wtab[56];
+    cf wreg[7];
+    if (W_LDS) {
+        if (tid < 56) wtab[tid] = p.tw[R * (tid % 7 + 1) * (tid / 7)];
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int r = 1; r < 8; ++r) w[r - 1] = p.tw[R * r * t];
+        for (int r = 1; r < 8; ++r) wreg[r - 1] = p.tw[R * r * t];
+    }
+    const cf *w = W_LDS ? wtab + 7 * t : wreg;
     cf tA[7];                                       // W_R^(u j)
 #pragma unroll
     for (int j = 1; j < 8; ++j) tA[j - 1] = Q > 1 ? p.tw[64 * u * j] : make_float2(1.f, 0.f);
@@ -414,9 +425,10 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_TX) void k_tx_mid(MidTxParams p) {
 
     if (tid < 16) lvl[tid] = p.bps > 1 && tid < (1 << (p.bps >> 1)) ? axis_level((unsigned)tid, p.bps >> 1) : 0.f;
     const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbw);
-    cf w[7];
-#pragma unroll
-    for (int r = 1; r < 8; ++r) { const cf x = p.tw[R * r * t]; w[r - 1] = make_float2(x.x, -x.y); }
+    __shared__ cf wtab[56];                         // conj W64^(r t), r = 1 .. 7: read at use (fourteen registers less: see k_demod_mid)
+    if (tid < 56) { const cf x = p.tw[R * (tid % 7 + 1) * (tid / 7)]; wtab[tid] = make_float2(x.x, -x.y); }
+    __syncthreads();
+    const cf *w = wtab + 7 * t;
     cf tA[7];
 #pragma unroll
     for (int j = 1; j < 8; ++j) { const cf x = Q > 1 ? p.tw[64 * u * j] : make_float2(1.f, 0.f); tA[j - 1] = make_float2(x.x, -x.y); }
@@ -579,9 +591,10 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     if (tid < (1 << p.bps)) ptab[tid] = map_point((unsigned)tid, p.bps);
     const unsigned fmask = (1u << p.bps) - 1u;
     if (l < 2) sbw[2 * LPS + l] = 0u;               // slack for the two-byte window
-    cf w[7];
-#pragma unroll
-    for (int r = 1; r < 8; ++r) { const cf x = p.tw[R * r * t]; w[r - 1] = make_float2(x.x, -x.y); }
+    __shared__ cf wtab[56];                         // conj W64^(r t), r = 1 .. 7: read at use (fourteen registers less: see k_demod_mid)
+    if (tid < 56) { const cf x = p.tw[R * (tid % 7 + 1) * (tid / 7)]; wtab[tid] = make_float2(x.x, -x.y); }
+    __syncthreads();
+    const cf *w = wtab + 7 * t;
     cf tA[7];
 #pragma unroll
     for (int j = 1; j < 8; ++j) { const cf x = Q > 1 ? p.tw[64 * u * j] : make_float2(1.f, 0.f); tA[j - 1] = make_float2(x.x, -x.y); }
