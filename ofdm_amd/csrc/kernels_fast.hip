@@ -1348,11 +1348,11 @@ __global__ __launch_bounds__(512, 4) void k_txframe4096(TxFrame4096Params p) {
                     __syncthreads(); // every wavefront has read its stage-B inputs out of T; the byte window is free
                     continue;
                 }
-                const float mx = fmaxf(p.header_max, __uint_as_float(*fmax));
+                const float sc = (1.0f / N) / fmaxf(p.header_max, __uint_as_float(*fmax));   // one division, then multiplies (<= 1 ulp)
                 __syncthreads(); // every wavefront has read its stage-B inputs out of T
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    T[(t + 8 * q) * TS + (col ^ (t & 6))] = make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
+                    T[(t + 8 * q) * TS + (col ^ (t & 6))] = make_float2(v[q].x * sc, v[q].y * sc);
                 __syncthreads();
                 {   // prefix_block: out = [x[N - CP .. N), x[0 .. N)], 16 bytes per lane
                     float4 *dst4 = reinterpret_cast<float4 *>(row + (long long)(10 + k) * S);
@@ -1368,12 +1368,19 @@ __global__ __launch_bounds__(512, 4) void k_txframe4096(TxFrame4096Params p) {
             }
             if (pass == 0) { // header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
                 __syncthreads();
-                const float mx = fmaxf(p.header_max, __uint_as_float(*fmax));
+                const float inv = 1.0f / fmaxf(p.header_max, __uint_as_float(*fmax));
                 float4 *dst4 = reinterpret_cast<float4 *>(row);
                 const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
-                for (int i = tid; i < 5 * S; i += 512) {
-                    const float4 h = h4[i];
-                    dst4[i] = make_float4(h.x / mx, h.y / mx, h.z / mx, h.w / mx);
+                // four table reads in flight per lane, then their four stores; unconditional reads from a clamped index
+                for (int i0 = tid; i0 < 5 * S; i0 += 4 * 512) {
+                    float4 h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int i = i0 + 512 * j; h[j] = h4[i < 5 * S ? i : 5 * S - 1]; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = i0 + 512 * j;
+                        if (i < 5 * S) dst4[i] = make_float4(h[j].x * inv, h[j].y * inv, h[j].z * inv, h[j].w * inv);
+                    }
                 }
             }
         }

@@ -614,27 +614,38 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     }
     const int sym_bytes = ND * p.bps / 8;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.payload) | (uintptr_t)p.payload_stride) & 3) == 0;
-    // stream bytes by .. by + 3 of a frame: [16-byte little-endian length | payload | zeros] (src/packets/mod.rs:20-32)
-    auto dword = [&](const uint8_t *pay, long long len, long long by) -> unsigned {
-        if (by < 16) return by < 8 ? (unsigned)((unsigned long long)len >> (8 * by)) : 0u;
-        const long long off = by - 16;
-        if (aligned && (off & 3) == 0 && off + 4 <= len) return *reinterpret_cast<const unsigned *>(pay + off);
-        unsigned v = 0;
-        for (int j = 0; j < 4; ++j) if (off + j < len) v |= (unsigned)pay[off + j] << (8 * j);
-        return v;
-    };
     const int slots = p.fpw * p.D, steps = (slots + G - 1) / G;
     const long long rounds = (p.n_frames + p.fpw - 1) / p.fpw;
 
+    // The stream bytes of symbol (f, k) -- two dwords per lane -- and the frame's length are REQUESTED one item ahead (issue_sym) and
+    // taken out of the registers when the symbol is built (settle in build): read where they were used, the length and each dword cost a
+    // dependent round trip per symbol, and every `s_waitcnt vmcnt(0)` behind such a load also waited for the PREVIOUS symbol's stores to be
+    // acknowledged (round-5 ISA scan: eleven serialized memory round trips per N = 256 frame).  The loads are unconditional: a row is
+    // readable for payload_bytes whatever its own length (include/ofdm_hip.h), the verdict is taken at the settle (paydw_settle).
+    struct Pre { unsigned d0, d1; int len_raw; };
+    auto issue_sym = [&](bool valid, long long f, int k, Pre &pr) {
+        const long long fc = valid ? f : 0;
+        const uint8_t *pay = p.payload + fc * p.payload_stride;
+        const long long by0 = (long long)k * sym_bytes + 4 * l - 16, by1 = by0 + 4 * LPS;   // payload byte of this lane's two dwords
+        pr.d0 = paydw_issue(pay, by0, p.payload_bytes, valid && 4 * l < sym_bytes, aligned, p.tw);
+        pr.d1 = paydw_issue(pay, by1, p.payload_bytes, valid && 4 * (l + LPS) < sym_bytes, aligned, p.tw);
+        pr.len_raw = p.payload_len ? p.payload_len[fc] : p.payload_bytes;
+    };
     // builds symbol (f, k): v[q] = N x[cB + R (t + 8 q)] (everything before the 1/N scale of k_tx_mid)
-    auto build = [&](bool valid, long long f, int k, cf *v) {
+    auto build = [&](bool valid, long long f, int k, cf *v, const Pre &pr) {
         long long len = 0;
         if (valid) {
-            len = p.payload_len ? row_len(p.payload_len[f], p.payload_bytes) : p.payload_bytes;
+            len = row_len(pr.len_raw, p.payload_bytes);
             const uint8_t *pay = p.payload + f * p.payload_stride;
             const long long sb0 = (long long)k * sym_bytes;
-            sbw[l] = 4 * l < sym_bytes ? dword(pay, len, sb0 + 4 * l) : 0u;
-            sbw[l + LPS] = 4 * (l + LPS) < sym_bytes ? dword(pay, len, sb0 + 4 * (l + LPS)) : 0u;
+            // stream bytes of a frame: [16-byte little-endian length | payload | zeros] (src/packets/mod.rs:20-32)
+            auto word = [&](unsigned raw, long long sb, bool want) -> unsigned {
+                if (!want) return 0u;
+                if (sb < 16) return sb < 8 ? (unsigned)((unsigned long long)len >> (8 * sb)) : 0u;
+                return paydw_settle(raw, pay, sb - 16, len, true, aligned);
+            };
+            sbw[l] = word(pr.d0, sb0 + 4 * l, 4 * l < sym_bytes);
+            sbw[l + LPS] = word(pr.d1, sb0 + 4 * (l + LPS), 4 * (l + LPS) < sym_bytes);
         }
         symbol_sync<LPS>();
         long long left = 16 + len - (long long)k * sym_bytes;   // stream bytes that belong to this symbol
@@ -663,11 +674,13 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     auto emit = [&](bool valid, long long f0, int fl, int k, const cf *v, auto raw_tag) {
         constexpr bool RAW = decltype(raw_tag)::value;
         const float mx = RAW ? 1.f : fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
+        // ONE division per lane and symbol, then multiplies (<= 1 ulp from the two roundings x / N, / max of the staged path -- inside the
+        // 1e-5 of the parity rule): sixteen IEEE divisions per lane and symbol were half of this kernel's arithmetic (round 5)
+        const float sc = RAW ? 1.0f / N : (1.0f / N) / mx;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = cB + R * (t + 8 * q);
-            Tsym[M::t2_index(n)] = RAW ? make_float2(v[q].x * (1.0f / N), v[q].y * (1.0f / N))
-                                       : make_float2(v[q].x * (1.0f / N) / mx, v[q].y * (1.0f / N) / mx);
+            Tsym[M::t2_index(n)] = make_float2(v[q].x * sc, v[q].y * sc);
         }
         symbol_sync<LPS>();
         if (valid) {
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     // two-pass kernel: x / N, then / max) and stores them again, now with the cyclic prefix.
     auto rescale = [&](bool valid, long long f0, int fl, int k) {
         if (!valid) return;
-        const float mx = fmaxf(p.header_max, __uint_as_float(fmax[fl]));
+        const float inv = 1.0f / fmaxf(p.header_max, __uint_as_float(fmax[fl]));
         float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride + (long long)(10 + k) * S);
         float4 y[4];
 #pragma unroll
@@ -695,7 +708,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = l + LPS * j;
-            const float4 o = make_float4(y[j].x / mx, y[j].y / mx, y[j].z / mx, y[j].w / mx);
+            const float4 o = make_float4(y[j].x * inv, y[j].y * inv, y[j].z * inv, y[j].w * inv);
             dst4[(CP >> 1) + i] = o;
             if (j == 3) dst4[i - ((N - CP) >> 1)] = o;
         }
@@ -712,58 +725,93 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     // ---- header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
     auto emit_headers = [&](long long f0) {
         for (int fl = 0; fl < p.fpw && f0 + fl < p.n_frames; ++fl) {
-            const float mx = fmaxf(p.header_max, __uint_as_float(fmax[fl]));
+            const float inv = 1.0f / fmaxf(p.header_max, __uint_as_float(fmax[fl]));   // one division, then multiplies (<= 1 ulp)
             float4 *dst4 = reinterpret_cast<float4 *>(p.out + (f0 + fl) * p.out_stride);
             const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
-            for (int i = tid; i < 5 * S; i += 256) {
-                const float4 h = h4[i];
-                dst4[i] = make_float4(h.x / mx, h.y / mx, h.z / mx, h.w / mx);
+            // four table reads in flight per lane, then their four stores (one load, its wait and its store at a time cost 5 S / 256
+            // dependent round trips per frame); the reads are unconditional from a clamped index, only the stores are predicated
+            for (int i0 = tid; i0 < 5 * S; i0 += 4 * 256) {
+                float4 h[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int i = i0 + 256 * j; h[j] = h4[i < 5 * S ? i : 5 * S - 1]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + 256 * j;
+                    if (i < 5 * S) dst4[i] = make_float4(h[j].x * inv, h[j].y * inv, h[j].z * inv, h[j].w * inv);
+                }
             }
         }
     };
 
+    // item = (round, step): its symbol slot sigma = step * G + g of the round's fpw x D slots
+    auto item_sym = [&](long long round, int step, long long &f, int &fl, int &k, bool &valid) {
+        const int sigma = step * G + g;
+        fl = sigma / p.D; k = sigma - fl * p.D;
+        f = round * p.fpw + fl;
+        valid = round < rounds && sigma < slots && f < p.n_frames;
+    };
+    Pre pre;
+    {   // the first item's bytes
+        long long f; int fl, k; bool valid;
+        item_sym(blockIdx.x, 0, f, fl, k, valid);
+        issue_sym(valid, f, k, pre);
+    }
     for (long long round = blockIdx.x; round < rounds; round += gridDim.x) {
         if (tid < 32) fmax[tid] = 0u;
-        __syncthreads();
+        lds_barrier();   // (LDS only: a __syncthreads() here also waited for the previous round's stores to be acknowledged)
         const long long f0 = round * p.fpw;
         if (KEEP > 0) { // steps <= KEEP (launcher): build once, keep, scale, store
             cf vv[KEEP > 0 ? KEEP : 1][8];
 #pragma unroll
             for (int step = 0; step < KEEP; ++step) {
                 if (step < steps) {
-                    const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
-                    const bool valid = sigma < slots && f0 + fl < p.n_frames;
-                    build(valid, f0 + fl, k, vv[step]);
+                    long long f; int fl, k; bool valid;
+                    item_sym(round, step, f, fl, k, valid);
+                    const Pre cur = pre;
+                    {   // the next item: the next step of this round, or the first of the workgroup's next round
+                        long long fn; int fln, kn; bool vn;
+                        if (step + 1 < steps) item_sym(round, step + 1, fn, fln, kn, vn); else item_sym(round + gridDim.x, 0, fn, fln, kn, vn);
+                        issue_sym(vn, fn, kn, pre);
+                    }
+                    build(valid, f, k, vv[step], cur);
                     note_max(valid, fl, vv[step]);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             emit_headers(f0);
 #pragma unroll
             for (int step = 0; step < KEEP; ++step) {
                 if (step < steps) {
-                    const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
-                    const bool valid = sigma < slots && f0 + fl < p.n_frames;
+                    long long f; int fl, k; bool valid;
+                    item_sym(round, step, f, fl, k, valid);
                     emit(valid, f0, fl, k, vv[step], std::false_type{});
                 }
             }
-            __syncthreads(); // fmax is reset by the next round
+            lds_barrier(); // fmax is reset by the next round
             continue;
         }
         if (KEEP < 0) { // build once: unnormalised samples out, the frame's maximum, then the rescale sweep over what was just written
             for (int step = 0; step < steps; ++step) {
-                const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
-                const bool valid = sigma < slots && f0 + fl < p.n_frames;
+                long long f; int fl, k; bool valid;
+                item_sym(round, step, f, fl, k, valid);
+                const Pre cur = pre;
+                {
+                    long long fn; int fln, kn; bool vn;
+                    if (step + 1 < steps) item_sym(round, step + 1, fn, fln, kn, vn); else item_sym(round + gridDim.x, 0, fn, fln, kn, vn);
+                    issue_sym(vn, fn, kn, pre);
+                }
                 cf v[8];
-                build(valid, f0 + fl, k, v);
+                build(valid, f, k, v, cur);
                 note_max(valid, fl, v);
                 emit(valid, f0, fl, k, v, std::true_type{});
             }
             __syncthreads(); // every maximum of the round is final (and this thread's stores are acknowledged: s_waitcnt vmcnt(0))
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             emit_headers(f0);
             for (int step = 0; step < steps; ++step) {
-                const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
-                rescale(sigma < slots && f0 + fl < p.n_frames, f0, fl, k);
+                long long f; int fl, k; bool valid;
+                item_sym(round, step, f, fl, k, valid);
+                rescale(valid, f0, fl, k);
             }
             __syncthreads(); // fmax is reset by the next round
             continue;
@@ -772,19 +820,27 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
         // builder, the pass is a uniform branch around its two epilogues (two inlined instances spill at 4 waves per SIMD).
         for (int pass = 0; pass < 2; ++pass) {
             for (int step = 0; step < steps; ++step) {
-                const int sigma = step * G + g, fl = sigma / p.D, k = sigma - fl * p.D;
-                const bool valid = sigma < slots && f0 + fl < p.n_frames;
+                long long f; int fl, k; bool valid;
+                item_sym(round, step, f, fl, k, valid);
+                const Pre cur = pre;
+                {   // the next item: next step, the first step of pass 1, or the first step of the workgroup's next round
+                    long long fn; int fln, kn; bool vn;
+                    if (step + 1 < steps) item_sym(round, step + 1, fn, fln, kn, vn);
+                    else if (pass == 0) item_sym(round, 0, fn, fln, kn, vn);
+                    else item_sym(round + gridDim.x, 0, fn, fln, kn, vn);
+                    issue_sym(vn, fn, kn, pre);
+                }
                 cf v[8];
-                build(valid, f0 + fl, k, v);
+                build(valid, f, k, v, cur);
                 if (pass == 0) { note_max(valid, fl, v); continue; }
                 emit(valid, f0, fl, k, v, std::false_type{});
             }
             if (pass == 0) {
-                __syncthreads();
+                lds_barrier();
                 emit_headers(f0);
             }
         }
-        __syncthreads(); // fmax is reset by the next round
+        lds_barrier(); // fmax is reset by the next round
     }
 }
 
