@@ -382,13 +382,13 @@ def main():
     kern_s = ev_ms / 1e3 / a.steps
     alg_bytes = F * (syms * ctx.S * 8 + syms * ctx.bytes_per_symbol)  # 8 B/sample read + packed bytes written
     # HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_traffic.json, newest round), scaled to F: collected in
-    # separate --pmc runs of tools/pmc_traffic.py (counters cannot ride along with a timed run), NOT measured in this run
+    # separate --pmc runs of tools/pmc_traffic5.py (counters cannot ride along with a timed run), NOT measured in this run
     traffic = traffic_source = None
     for rnd in ("r05", "r04", "r03", "r02"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")))["k_demod64"]
             traffic = F * (pm["read_bytes_per_frame"] + pm["write_bytes_per_frame"])
-            traffic_source = f"profiles/{rnd}_pmc_traffic.json ({pm.get('counters', 'FETCH_SIZE / WRITE_SIZE')}; separate --pmc passes of tools/pmc_traffic.py on the same kernel and shape, not measured in this run)"
+            traffic_source = f"profiles/{rnd}_pmc_traffic.json ({pm.get('counters', 'FETCH_SIZE / WRITE_SIZE')}; separate --pmc passes of tools/pmc_traffic5.py on the same kernel and shape, not measured in this run)"
             break
         except Exception:
             pass

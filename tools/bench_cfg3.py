@@ -124,7 +124,7 @@ def _roof(bytes_, ms, **extra):
 
 
 def _traffic(kernels):
-    """HBM bytes per frame of the named kernels from the newest committed PMC pass (tools/pmc_traffic.py), or None."""
+    """HBM bytes per frame of the named kernels from the newest committed PMC pass (tools/pmc_traffic5.py), or None."""
     import json
     for rnd in ("r05", "r04", "r03"):
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{rnd}_pmc_traffic.json")
@@ -133,7 +133,7 @@ def _traffic(kernels):
             tot = 0.0
             for k in kernels:
                 tot += pm[k]["read_bytes_per_frame"] + pm[k].get("write_bytes_per_frame", 0.0)
-            return tot, f"profiles/{rnd}_pmc_traffic.json (separate --pmc passes of tools/pmc_traffic.py, not measured in this run)"
+            return tot, f"profiles/{rnd}_pmc_traffic.json (separate --pmc passes of tools/pmc_traffic5.py, not measured in this run)"
         except Exception:
             continue
     return None, None

@@ -1,10 +1,10 @@
 """One timed configuration per process, for `rocprofv3 --kernel-trace --stats` (tools/profile_round.sh): the kernels of the chosen
 block are launched ONLY in the measured configuration, so the profiler's per-kernel average is the number the bench block divides
-by (in the full bench run k_sc_cf<256,...> also runs over near-empty redo lists, and several legs share k_rxframe64).
+by (in the full bench run several legs share k_sc80 and k_rxframe64).
 
     python tools/prof_clean.py <which> [frames]
-      sc_every_lag   cfg3 frames, ofdm_sc_correlate_batch with one launch over every lag  (k_sc_cf<256,2,4,0,false>: the north-star kernel)
-      cfg3_chain     cfg3 frames, ofdm_rx_decode_batch over every lag (two-launch search + k_rxframe64)
+      sc_every_lag   cfg3 frames, ofdm_sc_correlate_batch over every lag (k_sc80, the exact streaming detector, + k_sc_post)
+      cfg3_chain     cfg3 frames, ofdm_rx_decode_batch over every lag (k_sc80 + k_sc_post + k_rx_prepare + k_rxframe64)
       cfg3_late      the late-packet / noise-only layout of tools/bench_cfg3.py, same call
       cfg4_chain     cfg4 ring, ofdm_rx_decode_batch over every lag (k_sc_stream + k_rxframe1024)
       cfg4_late      the late-packet layout of tools/bench_large_n.py, same call
