@@ -25,6 +25,7 @@ struct Tuning {
     long long grid_cap = 0;        // > 0: caps every persistent grid (test hook: many steps per workgroup on a small batch)
     int tx_waves = 16;             // k_txframe64: wavefronts per CU
     int txframe_keep_steps = 1;    // k_txframe_mid: 1 = frames whose data symbols fit ONE workgroup step (<= 32 / R symbols) are built once, their points kept in registers until the maximum is known; 0 = always twice
+    int no_txframe_optimistic = 0; // k_txframe_mid / k_txframe4096, frames of more than one step: 1 = the round-4 scheme (every symbol built twice: once for the frame maximum, once to be stored); 0 = symbols leave divided by the header maximum while the frame maximum forms, a round is rebuilt only if a frame exceeds it
     int txframe_rewrite = 0;       // k_txframe_mid, frames of more than one step: 1 = build every symbol ONCE -- unnormalised samples out, then a rescale sweep over what
                                    // was just written (L2 / memory-side cache) -- instead of building every symbol twice
     int sc_wg_per_cu = 7;          // k_sc_cf: persistent workgroups per CU

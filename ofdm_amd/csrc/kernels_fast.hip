@@ -1253,6 +1253,7 @@ struct TxFrame4096Params {
     float2 *out;
     long long out_stride; // samples
     int bps;
+    int optimistic;      // as k_txframe_mid: symbols leave divided by the header maximum; a frame that exceeds it is built again
 };
 
 template <bool GUARD>
@@ -1289,27 +1290,69 @@ __global__ __launch_bounds__(512, 4) void k_txframe4096(TxFrame4096Params p) {
     const int nd = GUARD ? 48 * 64 : N;
     const int sym_bytes = nd * p.bps / 8;   // <= 4096, a multiple of 4
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.payload) | (uintptr_t)p.payload_stride) & 3) == 0;
-    // stream bytes by .. by + 3 of a frame: [16-byte little-endian length | payload | zeros] (src/packets/mod.rs:20-32)
-    auto dword = [&](const uint8_t *pay, long long len, long long by) -> unsigned {
-        if (by < 16) return by < 8 ? (unsigned)((unsigned long long)len >> (8 * by)) : 0u;
-        const long long off = by - 16;
-        if (aligned && (off & 3) == 0 && off + 4 <= len) return *reinterpret_cast<const unsigned *>(pay + off);
-        unsigned v = 0;
-        for (int j = 0; j < 4; ++j) if (off + j < len) v |= (unsigned)pay[off + j] << (8 * j);
-        return v;
+    // The stream bytes of symbol (f, k) -- two dwords per lane -- and the frame's length are REQUESTED one symbol ahead and taken out of
+    // the registers when the symbol is built (paydw_issue / paydw_settle, as k_txframe_mid): read where they are used they cost a
+    // dependent round trip to HBM per symbol.  The barriers of this kernel are LDS-only (lds_barrier) so that the request stays in flight.
+    struct Pre { unsigned d0, d1; int len_raw; };
+    auto issue_sym = [&](bool valid, long long f, int k, Pre &pr) {
+        const long long fc = valid ? f : 0;
+        const uint8_t *pay = p.payload + fc * p.payload_stride;
+        const long long by0 = (long long)k * sym_bytes + 4 * tid - 16, by1 = by0 + 2048;   // payload byte of this lane's two dwords
+        pr.d0 = paydw_issue(pay, by0, p.payload_bytes, valid && 4 * tid < sym_bytes, aligned, p.tw);
+        pr.d1 = paydw_issue(pay, by1, p.payload_bytes, valid && 4 * (tid + 512) < sym_bytes, aligned, p.tw);
+        pr.len_raw = p.payload_len ? p.payload_len[fc] : p.payload_bytes;
     };
+    Pre pre;
+    issue_sym(blockIdx.x < p.n_frames, blockIdx.x, 0, pre);
 
     for (long long f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
         if (tid == 0) *fmax = 0u;
-        const long long len = p.payload_len ? row_len(p.payload_len[f], p.payload_bytes) : p.payload_bytes;
         const uint8_t *pay = p.payload + f * p.payload_stride;
         cf *row = p.out + f * p.out_stride;
+        // Optimistic scheme (kernels_mid.hip, k_txframe_mid): pass 0 builds every symbol once, notes its maximum and stores it
+        // divided by the header maximum; pass 1 -- every symbol again, divided by the true maximum -- runs only for a frame whose data
+        // exceeded the header (crafted payloads).  Without p.optimistic pass 0 only forms the maximum (the round-4 scheme, the A/B).
+        const bool opt = p.optimistic != 0;
         for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) { // header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
+                lds_barrier();
+                const float inv = 1.0f / fmaxf(p.header_max, __uint_as_float(*fmax));
+                float4 *dst4 = reinterpret_cast<float4 *>(row);
+                const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
+                // four table reads in flight per lane, then their four stores; unconditional reads from a clamped index
+                for (int i0 = tid; i0 < 5 * S; i0 += 4 * 512) {
+                    float4 h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int i = i0 + 512 * j; h[j] = h4[i < 5 * S ? i : 5 * S - 1]; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = i0 + 512 * j;
+                        if (i < 5 * S) dst4[i] = make_float4(h[j].x * inv, h[j].y * inv, h[j].z * inv, h[j].w * inv);
+                    }
+                }
+                if (opt && !(__uint_as_float(*fmax) > p.header_max)) break;
+            }
             for (int k = 0; k < p.D; ++k) {
                 const long long sb0 = (long long)k * sym_bytes;
-                sbw[tid] = 4 * tid < sym_bytes ? dword(pay, len, sb0 + 4 * tid) : 0u;
-                sbw[tid + 512] = 4 * (tid + 512) < sym_bytes ? dword(pay, len, sb0 + 4 * (tid + 512)) : 0u;
-                __syncthreads(); // the byte window is complete (and, first time round, fmax / ptab are set)
+                Pre cur;
+                if (opt && pass == 1) issue_sym(true, f, k, cur);   // the rare rebuild asks where it uses; `pre` keeps the next frame's
+                else {
+                    cur = pre;
+                    // the next item: the next symbol, the first symbol of pass 1 (two-pass scheme), or the first of the workgroup's next frame
+                    if (k + 1 < p.D) issue_sym(true, f, k + 1, pre);
+                    else if (pass == 0 && !opt) issue_sym(true, f, 0, pre);
+                    else issue_sym(f + gridDim.x < p.n_frames, f + gridDim.x, 0, pre);
+                }
+                const long long len = row_len(cur.len_raw, p.payload_bytes);
+                // stream bytes of a frame: [16-byte little-endian length | payload | zeros] (src/packets/mod.rs:20-32)
+                auto word = [&](unsigned raw, long long sb, bool want) -> unsigned {
+                    if (!want) return 0u;
+                    if (sb < 16) return sb < 8 ? (unsigned)((unsigned long long)len >> (8 * sb)) : 0u;
+                    return paydw_settle(raw, pay, sb - 16, len, true, aligned);
+                };
+                sbw[tid] = word(cur.d0, sb0 + 4 * tid, 4 * tid < sym_bytes);
+                sbw[tid + 512] = word(cur.d1, sb0 + 4 * (tid + 512), 4 * (tid + 512) < sym_bytes);
+                lds_barrier(); // the byte window is complete (and, first time round, fmax / ptab are set)
                 long long left = 16 + len - sb0;                     // stream bytes that belong to this symbol
                 left = left < 0 ? 0 : (left < sym_bytes ? left : sym_bytes);
                 const int live_bits = (int)(((unsigned)left * 8u + (unsigned)p.bps - 1u) / (unsigned)p.bps) * p.bps;
@@ -1326,7 +1369,7 @@ __global__ __launch_bounds__(512, 4) void k_txframe4096(TxFrame4096Params p) {
                 bfly8<true>(v);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) T[(t + 8 * q) * TS + (col ^ (t & 6))] = cmul(v[q], z[q]);
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = T[col * TS + (t ^ (col & 6)) + 8 * m];
                 bfly8<true>(v);
@@ -1345,15 +1388,18 @@ __global__ __launch_bounds__(512, 4) void k_txframe4096(TxFrame4096Params p) {
 #pragma unroll
                     for (int sh = 32; sh >= 1; sh >>= 1) mine = fmaxf(mine, __shfl_xor(mine, sh, 64));
                     if (lane == 0) atomicMax(fmax, __float_as_uint(mine));
-                    __syncthreads(); // every wavefront has read its stage-B inputs out of T; the byte window is free
-                    continue;
+                    if (!opt) {
+                        lds_barrier(); // every wavefront has read its stage-B inputs out of T; the byte window is free
+                        continue;
+                    }
                 }
-                const float sc = (1.0f / N) / fmaxf(p.header_max, __uint_as_float(*fmax));   // one division, then multiplies (<= 1 ulp)
-                __syncthreads(); // every wavefront has read its stage-B inputs out of T
+                // one division, then multiplies (<= 1 ulp)
+                const float sc = (1.0f / N) / (pass == 0 ? p.header_max : fmaxf(p.header_max, __uint_as_float(*fmax)));
+                lds_barrier(); // every wavefront has read its stage-B inputs out of T
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     T[(t + 8 * q) * TS + (col ^ (t & 6))] = make_float2(v[q].x * sc, v[q].y * sc);
-                __syncthreads();
+                lds_barrier();
                 {   // prefix_block: out = [x[N - CP .. N), x[0 .. N)], 16 bytes per lane
                     float4 *dst4 = reinterpret_cast<float4 *>(row + (long long)(10 + k) * S);
 #pragma unroll
@@ -1364,27 +1410,10 @@ __global__ __launch_bounds__(512, 4) void k_txframe4096(TxFrame4096Params p) {
                         if (j == 3) dst4[i - ((N - CP) >> 1)] = y;
                     }
                 }
-                __syncthreads(); // the byte window / T are reused by the next symbol
-            }
-            if (pass == 0) { // header blocks (src/transmitter.rs:22-34), divided by the frame maximum like the data
-                __syncthreads();
-                const float inv = 1.0f / fmaxf(p.header_max, __uint_as_float(*fmax));
-                float4 *dst4 = reinterpret_cast<float4 *>(row);
-                const float4 *h4 = reinterpret_cast<const float4 *>(p.header);
-                // four table reads in flight per lane, then their four stores; unconditional reads from a clamped index
-                for (int i0 = tid; i0 < 5 * S; i0 += 4 * 512) {
-                    float4 h[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { const int i = i0 + 512 * j; h[j] = h4[i < 5 * S ? i : 5 * S - 1]; }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = i0 + 512 * j;
-                        if (i < 5 * S) dst4[i] = make_float4(h[j].x * inv, h[j].y * inv, h[j].z * inv, h[j].w * inv);
-                    }
-                }
+                lds_barrier(); // the byte window / T are reused by the next symbol
             }
         }
-        __syncthreads(); // fmax is reset for the next frame
+        lds_barrier(); // fmax is reset for the next frame
     }
 }
 
@@ -1399,6 +1428,7 @@ hipError_t run_txframe4096(const SymParams &sp, const float2 *header, float head
     p.payload = sp.payload; p.payload_stride = sp.payload_stride; p.payload_len = sp.payload_len; p.payload_bytes = sp.payload_bytes;
     p.n_frames = sp.n_frames; p.D = sp.syms_per_frame; p.tw = sp.tw; p.header = header; p.header_max = header_max;
     p.out = sp.out; p.out_stride = sp.out_stride_s; p.bps = sp.bps;
+    p.optimistic = tuning_or_default(sp.tune).no_txframe_optimistic ? 0 : 1;
     const size_t lds = (size_t)(8 * 8 * 72 + 64 * 72) * sizeof(float2) + 4096 + 16 + 256 * sizeof(float2) + 16;
     hipError_t e = sp.guard ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_txframe4096<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                             : hipFuncSetAttribute(reinterpret_cast<const void *>(k_txframe4096<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -560,6 +560,7 @@ struct MidTxFrameParams {
     float2 *out;
     long long out_stride; // samples
     int bps;
+    int optimistic;      // 1: samples leave scaled by 1 / header_max while the frame's maximum forms; a round is rebuilt only when a frame exceeds it
 };
 
 // KEEP > 0: a round's symbols fit KEEP steps, so every lane KEEPS its KEEP x 8 points in registers while the round's maxima form and
@@ -671,9 +672,9 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
 
     // the samples of symbol (f0 + fl, k), divided by the frame's maximum, through T into sample order and out (prefix_block: out = [x[N - CP .. N), x[0 .. N)]).
     // RAW (the build-once scheme): the symbol's N samples go out UNNORMALISED (x 1 / N only) and without the prefix; rescale() finishes them.
-    auto emit = [&](bool valid, long long f0, int fl, int k, const cf *v, auto raw_tag) {
+    auto emit = [&](bool valid, long long f0, int fl, int k, const cf *v, auto raw_tag, bool header_only = false) {
         constexpr bool RAW = decltype(raw_tag)::value;
-        const float mx = RAW ? 1.f : fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
+        const float mx = RAW ? 1.f : header_only ? p.header_max : fmaxf(p.header_max, __uint_as_float(fmax[valid ? fl : 0]));
         // ONE division per lane and symbol, then multiplies (<= 1 ulp from the two roundings x / N, / max of the staged path -- inside the
         // 1e-5 of the parity rule): sixteen IEEE divisions per lane and symbol were half of this kernel's arithmetic (round 5)
         const float sc = RAW ? 1.0f / N : (1.0f / N) / mx;
@@ -816,28 +817,45 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
             __syncthreads(); // fmax is reset by the next round
             continue;
         }
-        // pass 0: the signed maximum of every frame of the round; pass 1: the samples, divided by it.  ONE instance of the symbol
-        // builder, the pass is a uniform branch around its two epilogues (two inlined instances spill at 4 waves per SIMD).
+        // The frame maximum (normalize, transmitter.rs:184-188) is max(header maximum, data maximum), and the constant header blocks
+        // carry the full-scale locking signal: with the reference's constellations a data symbol exceeds it only for payloads crafted
+        // to line the carriers up (re x[n] <= sqrt 2 against 1.0).  OPTIMISTIC scheme (round 5): pass 0 builds every symbol of the round
+        // once, notes its maximum and stores it divided by the HEADER maximum; only if a frame of the round turned out larger is the
+        // round built again (pass 1) and stored divided by the true maxima -- same thread, same addresses, program order.
+        // Without p.optimistic: pass 0 only forms the maxima, pass 1 stores (every symbol built twice; the A/B).
+        // ONE instance of the symbol builder, the pass is a uniform branch around it (two inlined instances spill at 4 waves per SIMD).
+        const bool opt = p.optimistic != 0;
         for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                lds_barrier();       // every maximum of the round is final
+                emit_headers(f0);
+                if (opt) {
+                    bool redo = false;
+                    for (int fl = 0; fl < p.fpw; ++fl) redo |= __uint_as_float(fmax[fl]) > p.header_max;
+                    if (!redo) break;
+                }
+            }
             for (int step = 0; step < steps; ++step) {
                 long long f; int fl, k; bool valid;
                 item_sym(round, step, f, fl, k, valid);
-                const Pre cur = pre;
-                {   // the next item: next step, the first step of pass 1, or the first step of the workgroup's next round
+                Pre cur;
+                if (opt && pass == 1) issue_sym(valid, f, k, cur);   // the rare rebuild asks for its bytes where it uses them; `pre` keeps the next round's
+                else {
+                    cur = pre;
+                    // the next item: next step, the first step of pass 1 (two-pass scheme), or the first step of the workgroup's next round
                     long long fn; int fln, kn; bool vn;
                     if (step + 1 < steps) item_sym(round, step + 1, fn, fln, kn, vn);
-                    else if (pass == 0) item_sym(round, 0, fn, fln, kn, vn);
+                    else if (pass == 0 && !opt) item_sym(round, 0, fn, fln, kn, vn);
                     else item_sym(round + gridDim.x, 0, fn, fln, kn, vn);
                     issue_sym(vn, fn, kn, pre);
                 }
                 cf v[8];
                 build(valid, f, k, v, cur);
-                if (pass == 0) { note_max(valid, fl, v); continue; }
-                emit(valid, f0, fl, k, v, std::false_type{});
-            }
-            if (pass == 0) {
-                lds_barrier();
-                emit_headers(f0);
+                if (pass == 0) {
+                    note_max(valid, fl, v);
+                    if (!opt) continue;
+                }
+                emit(valid, f0, fl, k, v, std::false_type{}, pass == 0);
             }
         }
         lds_barrier(); // fmax is reset by the next round
@@ -943,6 +961,7 @@ hipError_t run_txframe_mid(int n_fft, const SymParams &sp, const float2 *header,
     p.n_frames = sp.n_frames; p.D = sp.syms_per_frame; p.fpw = 1; p.tw = sp.tw; p.header = header; p.header_max = header_max;
     p.out = sp.out; p.out_stride = sp.out_stride_s; p.bps = sp.bps;
     const Tuning &tu = tuning_or_default(sp.tune);
+    p.optimistic = tu.no_txframe_optimistic ? 0 : 1;
     const long long cap = tu.grid_cap;
     const int keep_max = tu.txframe_keep_steps;   // 0 = always build twice (A/B)
     const int G = 32 / R, steps1 = (p.D + G - 1) / G;

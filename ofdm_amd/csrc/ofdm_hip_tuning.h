@@ -15,7 +15,8 @@
 //     sc_wg_per_cu, sc_first_lags, sc128_one_wave                     k_sc_cf (the filter pair): workgroups per CU, lags of the first
 //                         launch (0 = one launch), one wavefront per frame in the 128-chunk kernel
 //     demod64_wg_per_cu, demod64_burst (16 / 8 / 4 / 1), demod64_narrow_stores   k_demod64
-//     tx_waves, txframe_keep_steps, txframe_rewrite                   k_txframe64 / k_txframe_mid
+//     tx_waves, txframe_keep_steps, txframe_rewrite,                  k_txframe64 / k_txframe_mid / k_txframe4096
+//     no_txframe_optimistic
 //     scb_two_segments, scb_big_tiles                                 k_scb_chunks / k_scb_fine
 //   profile build only (libofdm_hip_profile.so): ablation exits and s_memtime section timers
 //     debug_demod64, debug_sc, debug_tx
@@ -36,6 +37,7 @@ OFDM_TUNE_KEY("no_rxframe64_split", no_rxframe64_split, false)
 OFDM_TUNE_KEY("tx_waves", tx_waves, false)
 OFDM_TUNE_KEY("txframe_keep_steps", txframe_keep_steps, false)
 OFDM_TUNE_KEY("txframe_rewrite", txframe_rewrite, false)
+OFDM_TUNE_KEY("no_txframe_optimistic", no_txframe_optimistic, false)
 OFDM_TUNE_KEY("sc_wg_per_cu", sc_wg_per_cu, false)
 OFDM_TUNE_KEY("sc_first_lags", sc_first_lags, false)
 OFDM_TUNE_KEY("sc128_one_wave", sc128_one_wave, false)

@@ -699,7 +699,8 @@ def test_tx_encode_batch(api, orc, n, mod, guard, nbytes, ecc):
                                                  (4096, 2, False, 2500)])
 def test_tx_encode_mid_frames(api, orc, n, mod, guard, nbytes):
     """k_txframe_mid / k_txframe4096 (encode in one HBM pass for N = 128 .. 4096 and for N = 64 frames of more than 56 data
-    symbols: every frame built twice, once for its maximum) against the oracle's encode, 11 frames with ragged payload lengths on a 2-workgroup grid (several rounds per workgroup, a last
+    symbols: symbols stored divided by the header maximum while the frame maximum forms; test_tx_encode_frames_louder_than_their_header
+    covers the rebuild) against the oracle's encode, 11 frames with ragged payload lengths on a 2-workgroup grid (several rounds per workgroup, a last
     round that is only partly filled).  src/transmitter.rs:11-58, 184-188."""
     import torch
     rng = np.random.default_rng(n + mod + nbytes)
@@ -722,6 +723,63 @@ def test_tx_encode_mid_frames(api, orc, n, mod, guard, nbytes):
         tail = frames[f, want.size:]
         assert tail.size % S == 0 and (tail.size == 0 or np.abs(tail).max() <= np.abs(frames[f, :want.size]).max())
         assert abs(max(frames[f].real.max(), frames[f].imag.max()) - 1.0) < 1e-6
+
+def loud_payload(orc, n, mod, nbytes, sym=1, seed=0):
+    """A payload whose data symbol `sym` has a time sample far above the header blocks' full scale (without guard bands every bin is a
+    data carrier: each carrier gets the constellation point whose contribution to sample 1 of the symbol is largest)."""
+    rng = np.random.default_rng(seed)
+    sym_bytes = n * mod // 8
+    pts = []
+    for pat in range(1 << mod):                       # the point of every bit pattern (LSB-first stream bits)
+        bits = np.array([(pat >> b) & 1 for b in range(8)], np.uint8)
+        pts.append(orc.modulate(bytes(np.packbits(bits, bitorder="little")), mod)[0])
+    pts = np.array(pts)
+    freq, used = orc.encode_block(np.arange(1, n + 1, dtype=np.float64) + 0j, n, False)
+    assert used == n
+    pos_of = {int(round(freq[p].real)) - 1: p for p in range(n)}     # where stream point i lands in the frequency vector
+    resp = np.empty(n, np.complex128)
+    for p in range(n):                                # what a unit at bin position p contributes to time sample 1
+        e = np.zeros(n, np.complex128)
+        e[p] = 1.0
+        resp[p] = orc.prefix_block(e)[n // 4 + 1]
+    pat = np.array([int(np.argmax((pts * resp[pos_of[i]]).real)) for i in range(n)])
+    bits = ((pat[:, None] >> np.arange(mod)[None, :]) & 1).astype(np.uint8).reshape(-1)
+    loud = np.packbits(bits, bitorder="little")
+    pay = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    lo = sym * sym_bytes - 16
+    assert loud.size == sym_bytes and lo >= 0 and lo + sym_bytes <= nbytes
+    pay[lo: lo + sym_bytes] = loud
+    return pay
+
+
+@pytest.mark.parametrize("n,mod,nsym", [(64, 2, 60), (128, 2, 20), (256, 6, 16), (1024, 4, 5), (4096, 2, 3)])
+def test_tx_encode_frames_louder_than_their_header(api, orc, n, mod, nsym):
+    """The frame encoders store every data symbol divided by the HEADER maximum while the frame's own maximum forms, and build a round
+    again only if a frame turned out louder than its header blocks (normalize, src/transmitter.rs:184-188 divides by the maximum of the
+    whole frame).  Ordinary payloads never are (the header carries the full-scale locking signal); these are crafted to be, 2.5 x: loud
+    and ordinary frames side by side in one workgroup round must equal the oracle and the build-twice scheme (tuning
+    no_txframe_optimistic) bit for bit."""
+    import torch
+    nbytes = nsym * (n * mod // 8) - 16
+    S = n + n // 4
+    pays = [np.random.default_rng(5).integers(0, 256, nbytes, dtype=np.uint8), loud_payload(orc, n, mod, nbytes, 1, 1),
+            np.random.default_rng(6).integers(0, 256, nbytes, dtype=np.uint8), loud_payload(orc, n, mod, nbytes, nsym - 1, 2),
+            loud_payload(orc, n, mod, nbytes, 2, 3), np.random.default_rng(7).integers(0, 256, nbytes, dtype=np.uint8),
+            np.zeros(nbytes, np.uint8)]
+    pay = np.stack(pays)
+    a = api.Context(n_fft=n, modulation=mod, guard_bands=False, tuning={"grid_cap": 2})
+    b = api.Context(n_fft=n, modulation=mod, guard_bands=False, tuning={"grid_cap": 2, "no_txframe_optimistic": 1})
+    fa = host(a.encode_batch(dev(a, pay)))
+    fb = host(b.encode_batch(dev(b, pay)))
+    assert a.last_dispatch() == b.last_dispatch() == ("k_txframe4096" if n == 4096 else "k_txframe_mid")
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+    louder = 0
+    for f in range(len(pays)):
+        want = orc.encode(bytes(pay[f]), False, mod, n)
+        assert rel_err(fa[f], want) <= TOL, f"frame {f}"
+        louder += max(want[:10 * S].real.max(), want[:10 * S].imag.max()) < 0.5
+    assert louder == 3
+
 
 # ------------------------------------------------------------------ a10: decode (RX pipeline), config 3 shape
 def run_decode_parity(api, orc, n, mod, guard, ecc, nbytes, nfr, span_extra, seed, snr_db=30.0, cfo_abs=False):
