@@ -176,7 +176,7 @@ __device__ __forceinline__ cf cfo_phasor(double turns, long long n) {
     double ph = turns * (double)n;
     ph -= rint(ph);                 // [-0.5, 0.5] turns, exact
     // the hardware sine / cosine take TURNS: 2 instructions, max abs error 1.3e-7 over the whole range on gfx950
-    // (tools/trig_probe.cpp; sincospif: 5e-8 for ~35 instructions)
+    // (tools/lab/trig_probe.cpp; sincospif: 5e-8 for ~35 instructions)
     const float t = (float)ph;
     return make_float2(__builtin_amdgcn_cosf(t), -__builtin_amdgcn_sinf(t));
 }
@@ -214,7 +214,7 @@ __device__ __forceinline__ unsigned axis_code(unsigned l, int m) {
 }
 // returns the bps-bit index: bit j = j-th bit of the point in stream order
 // clamp(f, 0, top) as ONE v_med3_f32 (v_max_f32 and v_min_f32 each cost what it costs: 4 cycles per wavefront on gfx950, twice a
-// v_add_f32 -- tools/ubench/valu_rate.hip); a NaN gives min3 of the operands = 0, as fminf(fmaxf(NaN, 0), top) did
+// v_add_f32 -- tools/lab/valu_rate.hip); a NaN gives min3 of the operands = 0, as fminf(fmaxf(NaN, 0), top) did
 __device__ __forceinline__ float clamp0(float f, float top) { return __builtin_amdgcn_fmed3f(f, 0.0f, top); }
 __device__ __forceinline__ unsigned axis_bits(float x, int m) {
     const int M = 1 << m;

@@ -32,7 +32,7 @@ struct Tuning {
     int sc128_one_wave = 1;        // k_sc_cf over <= 960 lags: one wavefront per frame (two chunks per lane, 15 frames per CU, no wavefront idling through the fine pass) instead of two (0: A/B); measured 1.46 -> 1.31 ms per 262 144 config-3 frames over all lags, 1.43 -> 1.25 bounded
     int sc_first_lags = 576;       // k_sc_cf, searches of >= twice as many lags: the lags the first launch looks at (0 = one launch over every lag).
                                    // 576 = a crossing up to lag 335 with its whole window of W = 240 lags: a packet that starts within ~250 samples of its slot.
-                                   // Round 3 used 384 (config 3's delay <= 64); round 4's sweep (tools/first_lags_sweep.py, 262 144 frames, one box): the first
+                                   // Round 3 used 384 (config 3's delay <= 64); round 4's sweep (round-4 script tools/first_lags_sweep.py, since removed, 262 144 frames, one box): the first
                                    // launch costs the same up to 576 lags (early packets: 0.48 ms at 384, 0.49 at 576, 0.71 from 592 on), while on late
                                    // packets (delay 1..401, 10 % empty slots) every lag more decides more frames: search 1.42 -> 0.93 ms, chain 2.05 -> 1.59 ms
     int demod64_wg_per_cu = 0;     // k_demod64: persistent workgroups per CU (0 = from the occupancy API)

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
             pv = (t == 7) ? v[4] : pv;
             pv = (t == 2) ? v[7] : pv;
             // mean angle in TURNS (sum of the four atan2pi values / 8), then the hardware sine / cosine, which take turns:
-            // max abs error 1.3e-7 over [-pi, pi] on gfx950 (tools/trig_probe.cpp; sincospif: 5e-8) for 2 instructions instead of ~35
+            // max abs error 1.3e-7 over [-pi, pi] on gfx950 (tools/lab/trig_probe.cpp; sincospif: 5e-8) for 2 instructions instead of ~35
             const float turns = sum8(__ocml_atan2pi_f32(pv.y, pv.x)) * 0.125f;
             rot = make_float2(__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns)); // applied inside the demapper (demap_point_rot)
         }

@@ -342,7 +342,7 @@ struct ScFastParams {
 //            turns them into CFO and metric one LANE per frame (an f64 atan2 costs the same for 64 frames as for one).
 // Anything the filter cannot settle (ambiguous crossing, > 4 candidates) goes to the slow list.
 // LDS: raw samples (18 KB for a 2176-sample frame) + 4.3 KB -> seven workgroups per CU.  Measured (OFDM_SC_DEBUG=10..17,
-// tools/sc_sections.py): per frame the DMA wait, phase 1, bases, coarse and fine sections take about 1.0 / 2.0 / 0.7 /
+// tools/lab/sc_sections.py): per frame the DMA wait, phase 1, bases, coarse and fine sections take about 1.0 / 2.0 / 0.7 /
 // 1.3 / 6.0 thousand s_memtime ticks; the fine wavefront is the critical path, which is why its LDS reads are issued
 // up front (one round trip per stage) and its reductions never touch LDS.
 //

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B (working tree vs _ab_base = a build of HEAD) of the R x 64 kernels: tools/ab_mid.sh [N ...]
+# Same-box A/B (working tree vs _ab_base = a build of HEAD) of the R x 64 kernels: tools/lab/ab_mid.sh [N ...]
 Ns=${@:-1024 2048}
 for rep in 1 2; do
 for d in . _ab_base; do

@@ -10,10 +10,5 @@ for l in sys.stdin:
     if l.startswith('{'):
         r=json.loads(l); print(r['n_fft'], 'tx %.3f rx %.3f enc %.3f'%(r['tx_ms'],r['rx_ms'],r['encode_ms']))
 ")
-  (cd $d && timeout -k 10 200 python tools/cfg3_ab.py 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        r=json.loads(l); print({k: round(v,3) for k,v in r.items() if k.endswith('_ms')})
-")
+  (cd $d && for w in cfg3_chain cfg3_late; do timeout -k 10 200 python tools/prof_clean.py $w 262144 2>/dev/null | cut -c1-120; done)
 done; done

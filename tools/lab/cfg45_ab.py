@@ -1,7 +1,7 @@
 """Quick A/B on one GPU: config-4 chain with the long-period Schmidl-Cox path (kernels_scbig.hip) against the round-1
-k_sc_tile path (tuning no_sc_big), and config-5 TX / RX.  python tools/cfg45_ab.py [cfg4|cfg5]"""
+k_sc_tile path (tuning no_sc_big), and config-5 TX / RX.  python tools/lab/cfg45_ab.py [cfg4|cfg5]"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tools import bench_large_n as b
 out = {}

@@ -1,8 +1,8 @@
 """Frame-level encode (k_txframe_mid / k_txframe4096): the optimistic one-pass scheme against the build-twice scheme (lab key
 no_txframe_optimistic), for D = 16 and D = 64 data symbols per frame (the header blocks are 10 / 26 and 10 / 74 of the frame), next to
-the continuous-stream TX rate of the same length.   python tools/enc_ab.py [log2 samples] [N ...]"""
+the continuous-stream TX rate of the same length.   python tools/lab/enc_ab.py [log2 samples] [N ...]"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ofdm_amd import api
 

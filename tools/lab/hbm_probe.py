@@ -2,9 +2,9 @@
    pattern 0  k_demod64's access (8-byte loads, cyclic prefix lines never touched: 512 of every 640 bytes)
    pattern 1  the same 8-byte loads over whole symbols
    pattern 2  unit-stride 16-byte loads
-and the torch copy / reduction the round-1 probe used.  python tools/hbm_probe.py [frames]"""
+and the torch copy / reduction the round-1 probe used.  python tools/lab/hbm_probe.py [frames]"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ofdm_amd import api
 

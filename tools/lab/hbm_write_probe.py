@@ -1,7 +1,7 @@
 """Write-side HBM ceilings next to the TX kernels' one-write roofline: a fill of 2 GiB (pure stores) and a device copy (reads +
-writes) through torch, timed with the library's HIP events.   python tools/hbm_write_probe.py"""
+writes) through torch, timed with the library's HIP events.   python tools/lab/hbm_write_probe.py"""
 import torch, time, json, sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ofdm_amd import api
 ctx = api.Context(n_fft=64, modulation=6, guard_bands=True)
 n = 1 << 28  # complex64 elements: 2 GiB

@@ -1,7 +1,7 @@
 """Does the headline kernel's time depend on whether its output buffer was allocated BEFORE or AFTER the 10 GB input (bench.py allocates
 it before)?  One process: two buffers before the input, six after; each timed over 10 launches, three rounds."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ofdm_amd import api
 import bench

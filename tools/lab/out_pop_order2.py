@@ -6,7 +6,7 @@
   small_out_x    256 allocations of 8 MB that stay, then output, then input
   hip_out_x      output from hipMalloc through the library (ofdm_dev_alloc), then input"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ofdm_amd import api
 import bench

@@ -1,5 +1,5 @@
 // Hardware probe for the packed-FP32 instructions of gfx950: does an instruction whose destination pair overlaps a source
-// pair still see the OLD source in its second (high) half?  (hipcc --offload-arch=gfx950 -O3 tools/pk_probe.cpp -o tools/pk_probe)
+// pair still see the OLD source in its second (high) half?  (hipcc --offload-arch=gfx950 -O3 tools/lab/pk_probe.cpp -o tools/pk_probe)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float cf __attribute__((ext_vector_type(2)));

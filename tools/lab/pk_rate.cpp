@@ -1,5 +1,5 @@
 // Issue-rate probe for gfx950: cycles per wave64 instruction of v_fma_f32, v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32 and v_fma_f64,
-// one wavefront per SIMD and four, 16 independent accumulators each (no dependent stalls).   hipcc --offload-arch=gfx950 -O3 tools/pk_rate.cpp -o tools/pk_rate
+// one wavefront per SIMD and four, 16 independent accumulators each (no dependent stalls).   hipcc --offload-arch=gfx950 -O3 tools/lab/pk_rate.cpp -o tools/pk_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f2 __attribute__((ext_vector_type(2)));

@@ -1,8 +1,8 @@
 """k_rxframe64 as one kernel with both frame bodies (tuning no_rxframe64_split = 1: round 3, three waves per SIMD) against the
 common-body / cut-body pair (four waves per SIMD for the common body), same process, same frames; results compared.
-python tools/rx64_ab.py [frames] [cut_every]   (cut_every > 0: every cut_every-th capture is cut short inside its data symbols)"""
+python tools/lab/rx64_ab.py [frames] [cut_every]   (cut_every > 0: every cut_every-th capture is cut short inside its data symbols)"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ofdm_amd import api
 from tools import bench_cfg3

@@ -1,8 +1,8 @@
 """k_sc80 (exact streaming detector, kernels_sc80.hip) against the round-4 f32 filter pair (tuning no_sc80 = 1) on config-3
 captures: per delay band the time of both searches over every lag, whether every timing index agrees, and the largest CFO / metric
-difference.  Run on the GPU box: python tools/sc80_ab.py [frames]"""
+difference.  Run on the GPU box: python tools/lab/sc80_ab.py [frames]"""
 import json, math, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ofdm_amd import api
 from tools import bench_cfg3, tune_env

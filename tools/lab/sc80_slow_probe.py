@@ -1,8 +1,8 @@
 """Which frames does k_sc80 hand to the slow list, and why?  Binary search on the batch with the stat counter, then prints the
 frame's delay and the oracle's view of the lags around the untrusted window."""
 import json, math, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 import torch
 from ofdm_amd import api

@@ -1,6 +1,6 @@
 """Profiling aid: per-section time of the Schmidl-Cox filter kernel (s_memtime ticks per frame, median over frames)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ofdm_amd import _lib, api
 from tools import bench_cfg3

@@ -2,7 +2,7 @@
 Producer wavefront: tile waits | sums + scans | barrier waits.  Consumer wavefront: bounds + lists | evaluations before the
 crossing | barrier waits | closing the window | whole frame."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import math
 import torch
 from ofdm_amd import _lib, api

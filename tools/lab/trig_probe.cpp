@@ -1,5 +1,5 @@
 // Accuracy probe for the hardware v_sin_f32 / v_cos_f32 (input in turns) against sincospif, on the GPU box:
-//   hipcc --offload-arch=gfx950 -O3 tools/trig_probe.cpp -o tools/trig_probe && tools/trig_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/lab/trig_probe.cpp -o tools/trig_probe && tools/trig_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
