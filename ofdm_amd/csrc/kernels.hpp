@@ -181,11 +181,12 @@ size_t sc_lds_bytes(const ScParams &p);
 // L = 80, W = 240 (N = 64): every lag on f64 prefix differences, one streaming pass that stops when the peak window has closed
 // (kernels_sc80.hip).  Leaves d_hat and the exact sums of the chosen lag (k_sc_post's input); frames it does not trust go to slow_list.
 bool sc80_ok(const ScParams &p);
+bool sc80_wanted(const ScParams &p);   // sc80_ok and enough frames (or short enough slots) for one row per frame to pay
 hipError_t launch_sc80(const ScParams &p, ScExact *exact, int32_t *slow_list, int32_t *slow_count, int num_cu, hipStream_t st);
 hipError_t run_sc(const ScParams &p, hipStream_t st);
 // fast path for one-tile frames with a short period (f32 filter + exact f64 decisions; kernels_sync.hip)
 bool sc_fast_ok(const ScParams &p);
-size_t sc_fast_workspace_bytes(long long n_frames, int W);
+size_t sc_fast_workspace_bytes(long long n_frames, long long n_lags);
 hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st);
 // periods L = 160 .. 1280 (N = 128 .. 1024): one streaming pass per frame that stops once the decision is determined
 // (kernels_scstream.hip)

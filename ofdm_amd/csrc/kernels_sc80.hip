@@ -347,6 +347,13 @@ bool sc80_ok(const ScParams &p) {
     return p.threshold > 0.0;
 }
 
+// k_sc80 handles a frame in ONE row of one wavefront (~0.2 Gsamples/s per row): right for batches, wrong for a handful of very long
+// captures, which the multi-tile search spreads over the whole chip.  Slots up to the one-tile size of the filter pair always take it
+// (as before round 5's extension); longer slots when the batch fills at least a sixteenth of the chip's 8 192 rows.
+bool sc80_wanted(const ScParams &p) {
+    return sc80_ok(p) && (p.n_lags + p.W + p.L <= 2560 || p.n_frames >= 512);
+}
+
 hipError_t launch_sc80(const ScParams &p, ScExact *exact, int32_t *slow_list, int32_t *slow_count, int num_cu, hipStream_t st) {
     if (p.n_frames <= 0) return hipSuccess;
     S80Params q;

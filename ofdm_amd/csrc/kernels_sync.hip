@@ -48,12 +48,15 @@ __global__ __launch_bounds__(SC_WG) void k_sc_tile(ScParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.L, W = p.W;
-    // slow-list mode: persistent workgroups redo the listed frames (one tile each); otherwise one (frame, tile) per block
-    const long long n_items = p.slow_list ? (long long)*p.slow_count : 1;
+    // slow-list mode: persistent workgroups redo the listed frames (tiles_per_frame tiles each: more than one only in mode 1, the
+    // first-crossing pass of a search over more lags than a tile holds); otherwise one (frame, tile) per block
+    const long long n_items = p.slow_list ? (long long)*p.slow_count * p.tiles_per_frame : 1;
   for (long long item = p.slow_list ? (long long)blockIdx.x : 0; item < n_items; item += p.slow_list ? (long long)gridDim.x : 1) {
     if (p.slow_list) __syncthreads();
-    const long long f = p.slow_list ? (long long)p.slow_list[item] : (long long)(blockIdx.x / p.tiles_per_frame);
-    const int tile = p.slow_list ? 0 : (int)(blockIdx.x - f * p.tiles_per_frame);
+    const long long unit = p.slow_list ? item : (long long)blockIdx.x;
+    const long long fi = unit / p.tiles_per_frame;
+    const long long f = p.slow_list ? (long long)p.slow_list[fi] : fi;
+    const int tile = (int)(unit - fi * p.tiles_per_frame);
 
     long long d0;
     if (p.mode == 2) {
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(SC_WG) void k_sc_tile(ScParams p) {
         int m01 = wmin[0] < wmin[1] ? wmin[0] : wmin[1], m23 = wmin[2] < wmin[3] ? wmin[2] : wmin[3];
         d1 = m01 < m23 ? m01 : m23;
         if (p.mode == 1) {
-            if (tid == 0) p.cross[blockIdx.x] = d1 == INT_MAX ? LLONG_MAX : d0 + d1;
+            if (tid == 0) p.cross[f * p.tiles_per_frame + tile] = d1 == INT_MAX ? LLONG_MAX : d0 + d1;
             continue;
         }
         if (d1 == INT_MAX) {
@@ -743,14 +746,34 @@ bool sc_fast_ok(const ScParams &p) {
     return p.mode == 0 && sc_fast_pick_nch(p) != 0 && p.L % 10 == 0 && p.W % 10 == 0 && p.W + 20 <= 320 &&
            (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (p.frame_stride & 1) == 0 && (p.frame_len & 1) == 0;
 }
-size_t sc_fast_workspace_bytes(long long n_frames, int /*W*/) {
-    return (size_t)n_frames * (sizeof(ScExact) + 2 * sizeof(int32_t)) + 128; // exact sums + slow list + redo list (+ their counters)
+// earliest crossing per frame over the tiles of a multi-tile search, for a device-side list of frames
+__global__ void k_sc_min_cross_list(const long long *cross, int tiles, const int32_t *list, const int32_t *count, int32_t *d1) {
+    const long long n = *count;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long f = list[i];
+        long long m = LLONG_MAX;
+        for (int t = 0; t < tiles; ++t) { long long c = cross[f * tiles + t]; m = c < m ? c : m; }
+        d1[f] = m == LLONG_MAX ? -1 : (int32_t)m;
+    }
+}
+// exact sums + slow list + redo list (+ their counters); a search over more lags than one k_sc_tile tile holds (k_sc80 on long slots)
+// also keeps the first crossing per (frame, tile) and per frame for the slow list's three-launch redo
+static long long sc_fast_tiles(long long n_lags) { return (n_lags + SC_CH - 1) / SC_CH; }
+size_t sc_fast_workspace_bytes(long long n_frames, long long n_lags) {
+    const long long tiles = sc_fast_tiles(n_lags);
+    size_t b = (size_t)n_frames * (sizeof(ScExact) + 2 * sizeof(int32_t)) + 128;
+    if (tiles > 1) b += (size_t)n_frames * (size_t)tiles * sizeof(long long) + (size_t)n_frames * sizeof(int32_t) + 64;
+    return b;
 }
 
-// p.mode == 0, p.tiles_per_frame == 1.  workspace: sc_fast_workspace_bytes(n_frames) bytes of device memory.
+// p.mode == 0, p.tiles_per_frame == 1.  workspace: sc_fast_workspace_bytes(n_frames, n_lags) bytes of device memory.
+// Callers: sc_fast_ok(p) (the filter pair can take the frame) or sc80_wanted(p) (k_sc80: any slot length).
 hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream_t st) {
     if (p.n_frames <= 0) return hipSuccess;
+    const Tuning &tu = tuning_or_default(p.tune);
+    const bool use80 = !tu.no_sc80 && sc80_wanted(p);
     const int nch = sc_fast_pick_nch(p);
+    if (!use80 && nch == 0) return hipErrorNotSupported;
     ScExact *exact = reinterpret_cast<ScExact *>(workspace);
     int32_t *slow_count = reinterpret_cast<int32_t *>(exact + p.n_frames);
     int32_t *slow_list = slow_count + 4;
@@ -762,20 +785,19 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     ScFastParams q;
     q.defer = 0; q.redo_list = redo_list; q.redo_count = redo_count; q.frame_list = nullptr; q.frame_count = nullptr;
     q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.frame_stride;
-    const long long tile_n = (long long)nch * 10;
+    const long long tile_n = (long long)(nch ? nch : 128) * 10;
     long long stage = p.frame_len < tile_n ? p.frame_len : tile_n;
     const long long needed = (p.n_lags + p.W + p.L + 10 + 1) & ~1LL; // the last searched lag's window, plus the slide's reach
     if (needed < stage) stage = needed;                        // bounded searches stage (and sum) only what they use
     q.n16 = (int)(stage / 2);
     q.n_lags = (int)p.n_lags; q.L = p.L; q.W = p.W;
-    const Tuning &tu = tuning_or_default(p.tune);
     q.debug = kProfile ? tu.debug_sc : 0;
     q.thr_lo = (float)(p.threshold * (1.0 - (double)SC_EPS));
     q.thr_hi = (float)(p.threshold * (1.0 + (double)SC_EPS));
     q.d_hat = p.d_hat; q.slow_list = slow_list; q.slow_count = slow_count; q.exact = exact;
     // persistent over the frames; workgroups per CU bounded by LDS (22.5 KB for a 2176-sample frame -> 7)
     const int per_cu_cap = tu.sc_wg_per_cu > 0 ? tu.sc_wg_per_cu : 7; // tuning knob
-    const size_t lds = sc_cf_lds_bytes(p.L, nch, stage);
+    const size_t lds = sc_cf_lds_bytes(p.L, nch ? nch : 128, stage);
     long long per_cu = (long long)(160 * 1024) / (long long)lds;
     if (per_cu > per_cu_cap) per_cu = per_cu_cap;
     if (per_cu < 1) per_cu = 1;
@@ -783,7 +805,7 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
     const long long gcap = tu.grid_cap > 0 ? tu.grid_cap : (1LL << 40);
     if (grid > gcap) grid = gcap;
     if (grid > p.n_frames) grid = p.n_frames;
-    if (!tu.no_sc80 && sc80_ok(p)) {
+    if (use80) {
         // N = 64 (L = 80, W = 240): every lag exactly, one streaming pass that stops when the peak window has closed (kernels_sc80.hip)
         if ((e = launch_sc80(p, exact, slow_list, slow_count, num_cu, st)) != hipSuccess) return e;
     } else if (nch == 256) {
@@ -856,9 +878,28 @@ hipError_t run_sc_fast(const ScParams &p, void *workspace, int num_cu, hipStream
         if (e != hipSuccess) return e;
     }
     long long g2 = p.n_frames < 512 ? p.n_frames : 512;
-    trace_add(p.trace, "k_sc_tile<list>");
-    hipLaunchKernelGGL(k_sc_tile, dim3((unsigned)g2), dim3(SC_WG), lds2, st, s);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const long long tiles = sc_fast_tiles(p.n_lags);
+    if (tiles <= 1) {
+        trace_add(p.trace, "k_sc_tile<list>");
+        hipLaunchKernelGGL(k_sc_tile, dim3((unsigned)g2), dim3(SC_WG), lds2, st, s);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else {
+        // more lags than one tile (k_sc80 on slots longer than 2 560 + W + L samples): first crossing per (listed frame, tile), the
+        // earliest per frame, then the peak window from there -- the three launches of the general multi-tile search, over the list
+        if (tiles > 0x7fffffff) return hipErrorInvalidValue;
+        long long *cross = reinterpret_cast<long long *>(reinterpret_cast<unsigned char *>(workspace) +
+                                                         (((size_t)p.n_frames * (sizeof(ScExact) + 2 * sizeof(int32_t)) + 128 + 7) & ~(size_t)7));
+        int32_t *d1 = reinterpret_cast<int32_t *>(cross + p.n_frames * tiles);
+        trace_add(p.trace, "k_sc_tile<list,cross>+k_sc_tile<list,peak>");
+        s.tiles_per_frame = (int)tiles; s.mode = 1; s.cross = cross;
+        hipLaunchKernelGGL(k_sc_tile, dim3((unsigned)g2), dim3(SC_WG), lds2, st, s);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_sc_min_cross_list, dim3(64), dim3(256), 0, st, cross, (int)tiles, slow_list, slow_count, d1);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        s.tiles_per_frame = 1; s.mode = 2; s.lag_base = d1;
+        hipLaunchKernelGGL(k_sc_tile, dim3((unsigned)g2), dim3(SC_WG), lds2, st, s);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (p.stats && p.stats->dev) { // the counters leave the workspace: it may be regrown or reused before anyone asks for them
         if ((e = hipMemcpyAsync(p.stats->dev, slow_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
         p.stats->has_slow = true;

@@ -585,10 +585,11 @@ int ofdm_abi_sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t fra
         return OFDM_OK;
     }
     n_lags = p.n_lags;
-    // one-tile frames with a short period: coarse-then-fine f32 filter + exact f64 decisions (k_sc_cf)
-    if (sc_fast_ok(p)) {
+    // N = 64 (L = 80): k_sc80, every lag exactly in one streaming pass, whatever the slot length; its A/B predecessor (and the path
+    // of unaligned batches): one-tile frames through the coarse-then-fine f32 filter + exact f64 decisions (k_sc_cf)
+    if (sc_fast_ok(p) || (!c->tune.no_sc80 && sc80_wanted(p))) {
         void *wsp;
-        int rc = ws_get(c, 6, sc_fast_workspace_bytes(n_frames, p.W), &wsp);
+        int rc = ws_get(c, 6, sc_fast_workspace_bytes(n_frames, p.n_lags), &wsp);
         if (rc) return rc;
         HIP_TRY(c, run_sc_fast(p, wsp, c->num_cu, c->stream));
         return OFDM_OK;

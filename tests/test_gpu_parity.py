@@ -525,6 +525,62 @@ def test_sc80_streaming_detector_corner_cases(api, orc):
             assert abs(f_delta[f] - wfd) <= 1e-9 and abs(metric[f] - wm) <= 1e-6 * max(1.0, wm), f
 
 
+def test_sc80_on_slots_longer_than_one_tile(api, orc):
+    """N = 64 slots of more than 2 560 samples (BPSK frames of more than ~110 payload bytes: the reference's own modulation) used to
+    fall to the general multi-tile search, 12 x slower per byte; k_sc80 streams a slot of any length, so a batch of at least 512 such
+    slots takes it.  Packets early, late (crossing beyond the first 2 560 lags) and absent; a burst in front of a packet 75 dB down
+    sends frames to the slow list, which for more lags than one k_sc_tile tile is redone in three launches (first crossing per tile,
+    earliest per frame, peak window).  Every frame against the generic search (lab key no_sc80), a sample against the oracle; a
+    batch of 64 such slots keeps the multi-tile search (one row per frame would leave the chip empty)."""
+    rng = np.random.default_rng(8080)
+    tx = orc.encode(bytes(rng.integers(0, 256, 300, dtype=np.uint8)), True, orc.BPSK)
+    assert tx.size == 63 * 80
+    span, nfr = 9000, 520
+    caps = np.zeros((nfr, span), np.complex64)
+    kinds = []
+    for f in range(nfr):
+        kind = f % 5
+        if kind == 4:                                     # noise only
+            caps[f] = fc32(0.004 * (rng.standard_normal(span) + 1j * rng.standard_normal(span)))
+        else:
+            d = int(rng.integers(1, 200)) if kind < 2 else int(rng.integers(2700, 3600))
+            caps[f] = through_channel(orc, rng, tx, span, d, float((rng.random() * 1.9 - 0.95) * np.pi / 80), 30.0)
+            if kind == 1 or kind == 3:                    # burst, then the packet 75 dB down: prefix differences are not trusted
+                w = 1e-3 * wide(caps[f])
+                w[5:25] += 3.0 * (rng.standard_normal(20) + 1j * rng.standard_normal(20))
+                caps[f] = fc32(w)
+        kinds.append(kind)
+    a = api.Context(modulation=api.BPSK, guard_bands=True, tuning={"grid_cap": 24})
+    b = api.Context(modulation=api.BPSK, guard_bands=True, tuning={"no_sc80": 1})
+    x = dev(a, caps)
+    da, fa, ma = (host(t) for t in a.sc_correlate(x))
+    assert a.last_dispatch() == "k_sc80+k_sc_tile<list,cross>+k_sc_tile<list,peak>", a.last_dispatch()
+    slow = a.get_tuning("stat_sc_slow_frames")
+    assert 100 <= slow <= 2 * (nfr // 5) + 8, slow
+    db, fb, mb = (host(t) for t in b.sc_correlate(dev(b, caps)))
+    assert b.last_dispatch().startswith("k_sc_tile<cross>"), b.last_dispatch()
+    assert np.array_equal(da, db)
+    found = da >= 0
+    assert found.sum() >= 4 * (nfr // 5) - 2 and (da[np.array(kinds) == 4] == -1).all()
+    assert np.abs(fa[found] - fb[found]).max() <= 1e-12 and np.abs(ma[found] - mb[found]).max() <= 1e-6
+    assert (da[np.array(kinds) >= 2][da[np.array(kinds) >= 2] >= 0] > 2560).all()          # the late packets' crossings lie in the second tile
+    for f in list(range(10)) + [nfr - 3, nfr - 2, nfr - 1]:
+        wd, _, wm, wfd = orc.sc_sync(wide(caps[f]), 80, 3, 0, 0.5)
+        assert da[f] == wd, (f, kinds[f], int(da[f]), wd)
+        if wd >= 0:
+            assert abs(fa[f] - wfd) <= 1e-9 and abs(ma[f] - wm) <= 1e-6 * max(1.0, wm), f
+    # few long slots: the chip-wide multi-tile search stays
+    d64 = host(a.sc_correlate(dev(a, caps[:64]))[0])
+    assert a.last_dispatch().startswith("k_sc_tile<cross>"), a.last_dispatch()
+    assert np.array_equal(d64, da[:64])
+    # and the decode chain on such a batch: payloads back (the clean early / late packets)
+    r = a.decode_batch(x, max_symbols=53)
+    assert "k_sc80" in a.last_dispatch()
+    ln = host(r["len"])
+    clean = [f for f in range(nfr) if kinds[f] in (0, 2)]
+    assert (ln[clean] == 300).all()
+
+
 @pytest.mark.parametrize("sc_tuning", SC_DETECTORS)
 def test_sc_correlate_untrusted_f32_filter(api, orc, sc_tuning):
     # A strong burst ahead of the frame makes the prefix energy >> window energy, so the fast kernel's f32 filter must
