@@ -252,7 +252,7 @@ template <int BPS, bool GUARD, int MODE>
 __global__ __launch_bounds__(256, (MODE == 0 && GUARD) ? 4 : 3) void k_rxframe64(RxFrame64Params p) {
     constexpr int S = 80, CP = 16;
     constexpr int ND = GUARD ? 48 : 64;
-    constexpr int SYM_BYTES = ND * BPS / 8;   // multiple of 4 (checked by the launcher)
+    constexpr int SYM_BYTES = ND * BPS / 8;   // a multiple of 4, or 6 (BPSK with guard bands: the reference's default frame): eight symbols are whole dwords either way
     constexpr int REGION_DW = ND * BPS / 4;   // 8 symbols
     constexpr int SLAB = 8 * 72;
     __shared__ cf slab_all[4 * SLAB];
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && GUARD) ? 4 : 3) void k_rxframe64
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = vn[m];
             zm = zn;
-            const int ndw = count * (SYM_BYTES / 4);
+            const int ndw = (count * SYM_BYTES + 3) / 4;   // (6-byte symbols: an odd count ends in half a dword; its upper half is zero in the image and lies inside the row)
             if (p.final_out) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the image is complete
                 if (k0 == 0) { // bincode fixint little-endian u128 length (src/packets/mod.rs:20-32), then Vec::truncate
@@ -509,17 +509,18 @@ hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, in
                          long long final_stride, int32_t *final_len, const int32_t *frame_list, const int32_t *frame_count,
                          int32_t *cut_ws) {
     const int nd = sp.guard ? 48 : 64;
-    if ((nd * sp.bps / 8) % 4 != 0 || !sp.nsym_frame || sp.soft) return hipErrorNotSupported;
-    if ((reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3)) return hipErrorNotSupported;
+    if ((nd * sp.bps) % 16 != 0 || !sp.nsym_frame || sp.soft) return hipErrorNotSupported;   // whole bytes per symbol, whole dwords per 8 symbols
+    // raw rows are written with dword stores (the fused finish does not touch them)
+    const bool to_final = final_out && final_len && (reinterpret_cast<uintptr_t>(final_out) & 3) == 0 && (final_stride & 3) == 0;
+    if (!to_final && ((reinterpret_cast<uintptr_t>(sp.out_bytes) & 3) || (sp.out_stride & 3))) return hipErrorNotSupported;
     if (sp.n_frames <= 0) return hipSuccess;
     RxFrame64Params p;
     p.in = sp.in; p.n_frames = sp.n_frames; p.frame_stride = sp.frame_stride; p.frame_len = sp.frame_len;
     p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym = sp.nsym_frame; p.tw = sp.tw; p.inv_training = sp.inv_training;
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.hk = hk_out;
     p.final_out = nullptr; p.final_stride = 0; p.final_len = nullptr;
-    if (final_out && final_len && (reinterpret_cast<uintptr_t>(final_out) & 3) == 0 && (final_stride & 3) == 0) {
-        p.final_out = final_out; p.final_stride = final_stride; p.final_len = final_len;
-    } else if (final_out) return hipErrorNotSupported;
+    if (to_final) { p.final_out = final_out; p.final_stride = final_stride; p.final_len = final_len; }
+    else if (final_out) return hipErrorNotSupported;
     p.frame_list = frame_list; p.frame_count = frame_count;
     // The split pays when cut captures are the exception (measured on 1 M config-3 frames, same box: chain 4.98 -> 4.68 ms / 4.98 -> 4.88 ms on
     // two boxes; with EVERY capture cut short the pair costs 18 % more than the one kernel: a skip pass plus the list): it is used when the
@@ -537,7 +538,7 @@ hipError_t run_rxframe64(const SymParams &sp, float2 *hk_out, hipStream_t st, in
     case 4: return launch_rxframe<4>(p, sp.guard != 0, grid, st, split);
     case 6: return launch_rxframe<6>(p, sp.guard != 0, grid, st, split);
     case 8: return launch_rxframe<8>(p, sp.guard != 0, grid, st, split);
-    case 1: if (!sp.guard) return launch_rxframe<1>(p, false, grid, st, split); return hipErrorNotSupported;
+    case 1: return launch_rxframe<1>(p, sp.guard != 0, grid, st, split);
     default: return hipErrorNotSupported;
     }
 }

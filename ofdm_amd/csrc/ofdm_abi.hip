@@ -812,10 +812,11 @@ static int rx_decode_impl(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, in
     if (n_frames && (!in || !out || !out_len || !status)) return OFDM_ERR_INVALID;
     if (n_frames > 1 && frame_stride <= 0) return OFDM_ERR_INVALID;
     const int bps_bytes = c->bytes_per_symbol();
-    const int64_t raw_stride = (int64_t)max_symbols * bps_bytes;
+    const int64_t raw_bytes = (int64_t)max_symbols * bps_bytes;
+    const int64_t raw_stride = (raw_bytes + 3) & ~(int64_t)3;   // rows of the raw-byte workspace start on dwords (6-byte BPSK symbols: odd counts)
     // rows must hold what k_rx_finish can write: the whole body without an outer code, floor(body / 7) * 4 bytes after
     // Hamming(7,4) decoding (include/ofdm_hip.h)
-    const int64_t body_max = raw_stride > 16 ? raw_stride - 16 : 0;
+    const int64_t body_max = raw_bytes > 16 ? raw_bytes - 16 : 0;
     if (out_stride < (c->prm.ecc == OFDM_ECC_NONE ? body_max : (body_max / 7) * 4)) return OFDM_ERR_INVALID;
     if (!n_frames) return OFDM_OK;
     DeviceGuard dev_guard(c->device);

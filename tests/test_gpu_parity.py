@@ -913,7 +913,7 @@ def test_rx_decode_batch_variants(api, orc, n, mod, guard, ecc, nbytes, cfo_abs)
     assert errs / (6 * nbytes * 8) < 5e-3
 
 
-@pytest.mark.parametrize("mod,guard,grid_cap", [(6, True, 0), (6, True, 3), (2, False, 2), (4, True, 0)])
+@pytest.mark.parametrize("mod,guard,grid_cap", [(6, True, 0), (6, True, 3), (2, False, 2), (4, True, 0), (1, True, 0), (1, True, 2)])
 def test_rxframe64_common_and_cut_bodies_as_two_launches(api, orc, mod, guard, grid_cap):
     """Round 4: k_rxframe64 runs as a pair -- the common frame body alone (four waves per SIMD with guard bands) over every frame,
     the capture-cut body over the device-side list of the frames the first launch had to leave.  Roomy captures (room for a whole
@@ -921,7 +921,7 @@ def test_rxframe64_common_and_cut_bodies_as_two_launches(api, orc, mod, guard, g
     slot too short to decode: status, offset, CFO, length and bytes must equal the oracle's and the one-kernel form's
     (tuning no_rxframe64_split), with the list walked by a capped grid as well."""
     rng = np.random.default_rng(64 + mod + grid_cap)
-    nbytes = {6: 560, 2: 230, 4: 360}[mod]
+    nbytes = {6: 560, 2: 230, 4: 360, 1: 116 + 6 * grid_cap}[mod]   # BPSK with guard bands (6 bytes per symbol): 22 and 24 data symbols
     tune = {"grid_cap": grid_cap} if grid_cap else {}
     ctx = api.Context(n_fft=64, modulation=mod, guard_bands=guard, tuning=tune)
     one = api.Context(n_fft=64, modulation=mod, guard_bands=guard, tuning={**tune, "no_rxframe64_split": 1})
@@ -954,6 +954,39 @@ def test_rxframe64_common_and_cut_bodies_as_two_launches(api, orc, mod, guard, g
         if got != w["bytes"]:                                          # a decision on the oracle's own boundary (never seen on these seeds)
             assert sum(a != b for a, b in zip(got, w["bytes"])) <= 1, f
     assert n_cut >= 8 and (ra["status"] == 0).sum() >= nfr - 3          # the cut body did run, on several frames
+
+
+@pytest.mark.parametrize("ecc", [0, 1])
+def test_rx_decode_reference_default_frames_take_the_frame_kernel(api, orc, ecc):
+    """BPSK with guard bands -- the reference's own default, 6 bytes per symbol -- through k_rxframe64 (until round 5 its "whole dwords
+    per symbol" gate sent exactly this shape to the generic kernels): ragged symbol counts, odd and even, so that a frame's last
+    8-symbol group ends on half a dword, without and with the outer code (raw rows of an odd symbol count: stride rounded up to a dword)."""
+    import torch
+    rng = np.random.default_rng(600 + ecc)
+    ctx = api.Context(n_fft=64, modulation=api.BPSK, guard_bands=True, ecc=api.ECC_HAMMING74 if ecc else api.ECC_NONE)
+    maxb = 152 if ecc else 116                      # 47 / 22 data symbols per slot (the caller's rows of 116 bytes are dword-aligned: fused finish)
+    lens = [maxb, 0, 4, 8, 12, 52, maxb - 4, 36, maxb] if ecc else [maxb, 0, 1, 5, 6, 7, 50, 107, 111, 33, 2, maxb]   # 107 bytes: 21 symbols, half a dword at the end
+    D = ctx.data_symbols(maxb)
+    assert D == (47 if ecc else 22)
+    span = ctx.frame_samples(maxb) + 120
+    caps, pays = [], []
+    for ln in lens:
+        pay = bytes(rng.integers(0, 256, ln, dtype=np.uint8))
+        body = orc.hamming74_encode(pay) if ecc else pay
+        tx = orc.encode(body, True, orc.BPSK, 64)
+        caps.append(through_channel(orc, rng, tx, span, int(rng.integers(1, 70)), (rng.random() * 1.8 - 0.9) * np.pi / 80, 30.0))
+        pays.append(pay)
+    caps = np.stack(caps)
+    r = {k: host(v) for k, v in ctx.decode_batch(dev(ctx, caps), max_symbols=D).items()}
+    want_d = "k_rxframe64+k_rxframe64<cut,list>+k_rx_finish" if ecc else "k_rxframe64<finish>+k_rxframe64<cut,list>"
+    assert ctx.last_dispatch().endswith(want_d), ctx.last_dispatch()
+    for f, ln in enumerate(lens):
+        w = orc.decode_sc(wide(caps[f]), True, orc.BPSK, 64, max_symbols=D)
+        want = orc.hamming74_decode(w["bytes"])[0] if ecc else w["bytes"]
+        assert r["status"][f] == w["status"] == 0 and r["offset"][f] == w["offset"], f
+        assert r["len"][f] == len(want), (f, ln, int(r["len"][f]), len(want))
+        assert bytes(r["bytes"][f][: r["len"][f]]) == want, f
+        assert bytes(r["bytes"][f][: ln]) == pays[f], f
 
 
 @pytest.mark.parametrize("n,mod,guard", [(1024, 4, True), (1024, 6, False), (64, 6, True)])
