@@ -16,7 +16,7 @@
 //     place in its own 8 rows of it: 32 KB of LDS per workgroup instead of 44 KB -> 5 workgroups (10 wavefronts) per CU;
 //   * stage-A twiddles live in registers again (the prefetch registers are gone).
 // A frame whose start is an odd sample (8-byte aligned) is staged from the even sample below it and read with a one-sample shift;
-// items that touch the end of the capture (pad_chunk, receiver.rs:203-210) or an unaligned batch take a synchronous
+// items that touch the end of the capture (pad_chunk, receiver.rs:203-210) take a synchronous
 // load-and-store path into the same slot image.
 //
 // FFT1024 = 16 x 64:  X[c + 16 d] = sum_b W64^(b d) * [ W1024^(b c) * sum_a x[64 a + b] W16^(a c) ],  c < 16, d < 64
@@ -47,7 +47,7 @@ struct RxFrame1024Params {
     unsigned char *out;          // raw decoded bytes (unfused mode), nsym * bytes_per_symbol per frame
     long long out_stride;
     float2 *hk;                  // optional: channel estimate per frame (1024 bins)
-    int aligned;                 // `in` is 16-byte aligned and frame_stride even: LDS-DMA staging
+    int aligned;                 // `in` has its natural 8-byte alignment: LDS-DMA staging
     // fused finish (optional): final payload rows, 4-byte aligned; ecc = 1: Hamming(7,4)
     unsigned char *final_out;
     long long final_stride;
@@ -360,7 +360,7 @@ hipError_t run_rxframe1024(const SymParams &sp, float2 *hk_out, hipStream_t st, 
     p.in = sp.in; p.n_frames = sp.n_frames; p.frame_stride = sp.frame_stride; p.frame_len = sp.frame_len;
     p.offset = sp.offset; p.f_delta = sp.f_delta; p.nsym = sp.nsym_frame; p.tw = sp.tw; p.inv_training = sp.inv_training;
     p.out = sp.out_bytes; p.out_stride = sp.out_stride; p.hk = hk_out;
-    p.aligned = (reinterpret_cast<uintptr_t>(sp.in) & 15) == 0 && (sp.frame_stride & 1) == 0;
+    p.aligned = (reinterpret_cast<uintptr_t>(sp.in) & 7) == 0;   // LDS-DMA takes any 4-byte aligned source (tools/lab/glds_align.hip); rows of odd stride too
     p.final_out = nullptr; p.final_stride = 0; p.final_len = nullptr; p.ecc = ecc;
     // the frame's packed bytes (at most max_symbols symbols: out_stride of the raw rows) must fit the LDS image
     const bool fuse = final_out && final_len && (reinterpret_cast<uintptr_t>(final_out) & 3) == 0 && (final_stride & 3) == 0 &&

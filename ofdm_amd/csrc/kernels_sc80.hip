@@ -338,10 +338,12 @@ __global__ __launch_bounds__(64, 2) void k_sc80(S80Params p) {
     s8_wait_vm<0>();
 }
 
-// L = 80, W = 240, 16-byte aligned frames of even length (LDS-DMA in 16-byte units), four frames' row offsets in 32 bits
+// L = 80, W = 240, frames of even length (LDS-DMA in 16-byte units), four frames' row offsets in 32 bits
 bool sc80_ok(const ScParams &p) {
     if (p.mode != 0 || p.L != 80 || p.W != 240 || p.tiles_per_frame != 1) return false;
-    if ((reinterpret_cast<uintptr_t>(p.in) & 15) != 0 || (p.frame_stride & 1) != 0 || (p.frame_len & 1) != 0) return false;
+    // (LDS-DMA takes any 4-byte aligned global address -- tools/lab/glds_align.hip --, so rows need only their natural 8-byte alignment and
+    //  any stride; the slot length stays even: the stream is clamped in 16-byte units counted from the frame's first sample)
+    if ((reinterpret_cast<uintptr_t>(p.in) & 7) != 0 || (p.frame_len & 1) != 0) return false;
     if (p.n_lags <= 0 || p.n_lags + 319 > p.frame_len || p.frame_len > (1LL << 27)) return false;
     if (p.n_frames > 1 && (p.frame_stride <= 0 || p.frame_stride > (1LL << 27))) return false;
     return p.threshold > 0.0;

@@ -521,11 +521,11 @@ static size_t sc_stream_lds(int L, int W) {
     const int epn = (W + L) / 10 + 136, qn = W / 10 + 136;
     return (size_t)ring * sizeof(float2) + (size_t)(epn + 2 * qn) * sizeof(double) + (size_t)ST_LIVE * (4 * sizeof(double) + 8) + 32 + 32 + 64;
 }
-// one tile-aligned streaming pass: L = 160 .. 5120 (N = 128 .. 4096) with 80 | L, 16-byte aligned frames (LDS-DMA), lags that fit
+// one tile-aligned streaming pass: L = 160 .. 5120 (N = 128 .. 4096) with 80 | L, lags that fit
 // 32-bit intervals, rings that fit one CU's LDS (N = 4096: 100 KB, one frame per CU)
 bool sc_stream_ok(const ScParams &p) {
     if (p.mode != 0 || p.L % 80 != 0 || p.L < 160 || p.L > 5120 || p.W % p.L != 0 || p.W / p.L > 3) return false;
-    if ((reinterpret_cast<uintptr_t>(p.in) & 15) != 0 || (p.frame_stride & 1) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(p.in) & 7) != 0) return false;   // LDS-DMA takes any 4-byte aligned source (tools/lab/glds_align.hip): odd strides are fine
     if (sc_stream_lds(p.L, p.W) > 150 * 1024) return false;
     return p.n_lags > 0 && p.n_lags + p.W + p.L < (1LL << 30);
 }
