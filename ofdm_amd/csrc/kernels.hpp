@@ -165,6 +165,7 @@ struct ScParams {
     long long n_lags = 0;        // lags searched per frame (already clipped to the valid range)
     int L = 0, W = 0;            // period and window
     double threshold = 0.5;
+    bool tail_mapped = false;    // the sample behind every frame's last one is mapped memory (rows with slack, or not the batch's last row)
     int tiles_per_frame = 1;
     int mode = 0;                // 0 fused (single tile), 1 first-crossing only, 2 peak search from lag_base
     const int32_t *lag_base = nullptr; // mode 2: per-frame first lag (d1), -1 = skip

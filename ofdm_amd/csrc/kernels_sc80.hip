@@ -342,8 +342,11 @@ __global__ __launch_bounds__(64, 2) void k_sc80(S80Params p) {
 bool sc80_ok(const ScParams &p) {
     if (p.mode != 0 || p.L != 80 || p.W != 240 || p.tiles_per_frame != 1) return false;
     // (LDS-DMA takes any 4-byte aligned global address -- tools/lab/glds_align.hip --, so rows need only their natural 8-byte alignment and
-    //  any stride; the slot length stays even: the stream is clamped in 16-byte units counted from the frame's first sample)
-    if ((reinterpret_cast<uintptr_t>(p.in) & 7) != 0 || (p.frame_len & 1) != 0) return false;
+    //  any stride.  The stream is clamped in 16-byte units counted from the frame's first sample, so the kernel is given an EVEN slot length:
+    //  an odd one is rounded up -- the extra sample is read, never used: every lag's window ends at or before the true last sample -- when
+    //  that sample is mapped, i.e. when rows have slack; ofdm_abi_sc_run peels the last frame off a batch of tight odd rows)
+    if ((reinterpret_cast<uintptr_t>(p.in) & 7) != 0) return false;
+    if ((p.frame_len & 1) != 0 && !(p.tail_mapped || (p.n_frames > 1 ? p.frame_stride > p.frame_len : false))) return false;
     if (p.n_lags <= 0 || p.n_lags + 319 > p.frame_len || p.frame_len > (1LL << 27)) return false;
     if (p.n_frames > 1 && (p.frame_stride <= 0 || p.frame_stride > (1LL << 27))) return false;
     return p.threshold > 0.0;
@@ -359,7 +362,7 @@ bool sc80_wanted(const ScParams &p) {
 hipError_t launch_sc80(const ScParams &p, ScExact *exact, int32_t *slow_list, int32_t *slow_count, int num_cu, hipStream_t st) {
     if (p.n_frames <= 0) return hipSuccess;
     S80Params q;
-    q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.n_frames > 1 ? p.frame_stride : 0; q.frame_len = p.frame_len;
+    q.in = p.in; q.n_frames = p.n_frames; q.frame_stride = p.n_frames > 1 ? p.frame_stride : 0; q.frame_len = p.frame_len + (p.frame_len & 1);
     q.n_lags = (int)p.n_lags; q.threshold = p.threshold;
     q.d_hat = p.d_hat; q.exact = exact; q.slow_list = slow_list; q.slow_count = slow_count;
     const Tuning &tu = tuning_or_default(p.tune);

@@ -575,9 +575,10 @@ static bool sc_make_params(ofdm_ctx *c, const float2 *in, int64_t n_frames, int6
     return true;
 }
 
-int ofdm_abi_sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
-                    int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric) {
+static int sc_run_impl(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                       int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric, bool tail_mapped) {
     ScParams p;
+    p.tail_mapped = tail_mapped;
     if (!sc_make_params(c, in, n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric, p)) { // no lag fits
         HIP_TRY(c, hipMemsetAsync(d_hat, 0xFF, sizeof(int32_t) * (size_t)n_frames, c->stream));
         if (f_delta) HIP_TRY(c, hipMemsetAsync(f_delta, 0, sizeof(double) * (size_t)n_frames, c->stream));
@@ -630,6 +631,24 @@ int ofdm_abi_sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t fra
     p.tiles_per_frame = 1; p.mode = 2; p.lag_base = (const int32_t *)d1;
     HIP_TRY(c, run_sc(p, c->stream));
     return OFDM_OK;
+}
+
+int ofdm_abi_sc_run(ofdm_ctx *c, const float2 *in, int64_t n_frames, int64_t frame_stride, int64_t frame_len,
+                    int64_t n_lags, int32_t *d_hat, double *f_delta, float *metric) {
+    // Tight rows of odd length (stride == length): k_sc80 is given an even slot length, i.e. reads one sample past an odd slot -- the next
+    // row's first one, except behind the last row.  That row goes through the general paths on its own, the others through k_sc80.
+    if (n_frames > 1 && (frame_len & 1) && frame_stride == frame_len && !c->tune.no_sc80) {
+        ScParams head;
+        head.tail_mapped = true;
+        if (sc_make_params(c, in, n_frames - 1, frame_stride, frame_len, n_lags, d_hat, f_delta, metric, head) && sc80_wanted(head)) {
+            int rc = sc_run_impl(c, in, n_frames - 1, frame_stride, frame_len, n_lags, d_hat, f_delta, metric, true);
+            if (rc) return rc;
+            const int64_t l = n_frames - 1;
+            return sc_run_impl(c, in + l * frame_stride, 1, frame_len, frame_len, n_lags, d_hat + l, f_delta ? f_delta + l : nullptr,
+                               metric ? metric + l : nullptr, false);
+        }
+    }
+    return sc_run_impl(c, in, n_frames, frame_stride, frame_len, n_lags, d_hat, f_delta, metric, false);
 }
 
 int ofdm_sc_correlate_batch(ofdm_ctx *c, const ofdm_fc32 *in, int64_t n_frames, int64_t frame_stride,

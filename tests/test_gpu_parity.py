@@ -575,6 +575,17 @@ def test_streaming_detectors_on_rows_of_any_alignment(api, orc, n):
     for f in good:   # (the FIR channel's weak bins leave a stray byte error at 35 dB; parity with the oracle is the other tests' subject)
         got = bytes(rb["bytes"][f][: rb["len"][f]])
         assert len(got) == nbytes and sum(a != b for a, b in zip(got, pays[f])) <= 3, f
+    # odd slot lengths: with slack behind every row (stride = length + 1) and as tight rows (stride = length: k_sc80 takes all rows but
+    # the last, whose "one sample past the slot" would lie outside the batch)
+    odd = span - 1
+    want = [orc.sc_sync(wide(caps[f][:odd]), S, 3, 0, 0.5) for f in range(nfr)]
+    tight = torch.from_numpy(np.ascontiguousarray(caps[:, :odd])).to(ctx.device)
+    for x, flen, label in ((dev(ctx, caps), odd, "slack"), (tight, None, "tight")):
+        d, fdl, m = (host(t) for t in ctx.sc_correlate(x, frame_len=flen))
+        assert ctx.last_dispatch().startswith(want_search), (label, ctx.last_dispatch())
+        for f in range(nfr):
+            wd, _, wm, wfd = want[f]
+            assert d[f] == wd and (wd < 0 or (abs(fdl[f] - wfd) <= 1e-9 and abs(m[f] - wm) <= 1e-6)), (label, f)
 
 
 def test_sc80_on_slots_longer_than_one_tile(api, orc):
