@@ -870,11 +870,25 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     // Loads are issued without a branch (a load under `if (in range)` is followed by s_waitcnt vmcnt(0) at the join, i.e. is
     // synchronous): out-of-range elements read the twiddle table instead and are zeroed when they leave the prefetch registers.
     // room = samples from this lane's first one to the end of the capture (FRAME), 0 past the batch.
-    auto fetch = [&](long long sg, cf *dst, int &room) {
+    // FRAME: the frame's scalars (trimmed start, live symbols, CFO) are requested a step ahead (FS tq) and taken where the next
+    // prefetch starts: read where they were used, each was followed by s_waitcnt vmcnt(0) -- the start offset ahead of the sample
+    // prefetch, the symbol count right behind it (draining it), the CFO, then the channel in four more round trips (round-5 ISA scan).
+    struct FS { int off, ns; double fd; };
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));   // keeps the workgroup-uniform scalar loads vector loads (as scalar loads they are waited for where they are issued)
+    auto load_scalars = [&](bool in, long long fr_) -> FS {
+        const long long fr = (in ? fr_ : 0) + vzero;
+        FS r;
+        r.off = p.offset ? p.offset[fr] : 0;
+        r.ns = p.nsym_frame ? p.nsym_frame[fr] : p.syms_per_frame;
+        r.fd = p.f_delta ? p.f_delta[fr] : 0.0;
+        return r;
+    };
+    auto fetch = [&](long long sg, long long fr_, int kk, long long off_, cf *dst, int &room) {
         const bool in = sg < p.total;
-        const long long fr = in ? fn : 0;
-        const long long off = FRAME && p.offset ? p.offset[fr] : 0;
-        const long long n0 = off + (long long)(p.first_symbol + kn) * S + CP + col;
+        const long long fr = in ? fr_ : 0;
+        const long long off = FRAME ? off_ : 0;
+        const long long n0 = off + (long long)(p.first_symbol + kk) * S + CP + col;
         const cf *src = p.in + fr * p.frame_stride + n0;
         long long rm = FRAME ? p.frame_len - n0 : (long long)N;
         rm = in ? rm : 0;
@@ -913,26 +927,42 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
     for (int i = tid; i < IMG_DW; i += 512) img[i] = 0u;
     cf pre[8];
     int room_pre = 0;
-    fetch(blockIdx.x, pre, room_pre);
+    auto advance = [&](long long &ff, int &kk) { ff += p.step_f; kk += p.step_k; if (kk >= p.syms_per_frame) { kk -= p.syms_per_frame; ++ff; } };
+    // positions: the symbol being transformed (f0, k0), the one whose samples are prefetched (fn, kn), the one whose scalars are (f2, k2)
+    long long f0 = fn, f2; int k0 = kn, k2;
+    advance(fn, kn);
+    f2 = fn; k2 = kn; advance(f2, k2);
+    FS tq = FS{0, 0, 0.0};
+    int ns_cur = 0; double fd_cur = 0.0;
+    {
+        FS s0 = FS{0, 0, 0.0};
+        if (FRAME) s0 = load_scalars(blockIdx.x < p.total, f0);
+        fetch(blockIdx.x, f0, k0, s0.off, pre, room_pre);
+        ns_cur = __builtin_amdgcn_readfirstlane(s0.ns);
+        fd_cur = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(s0.fd)), __builtin_amdgcn_readfirstlane(__double2loint(s0.fd)));
+        if (FRAME) tq = load_scalars((long long)blockIdx.x + gridDim.x < p.total, fn);
+    }
     unsigned *pending = nullptr; // where the image currently in LDS belongs
 
     for (long long sg = blockIdx.x; sg < p.total; sg += gridDim.x) {
-        const long long f = fn;
-        const int k = kn;
-        fn += p.step_f; kn += p.step_k;
-        if (kn >= p.syms_per_frame) { kn -= p.syms_per_frame; ++fn; }
+        const long long f = f0;
+        const int k = k0;
         cf v[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = (!FRAME || 64 * (t + 8 * m) < room_pre) ? pre[m] : make_float2(0.f, 0.f);
-        fetch(sg + gridDim.x, pre, room_pre);
+        // the next symbol's scalars (requested a step ago, right behind this symbol's samples): workgroup-uniform -> SGPRs
+        const int off_n = FRAME ? __builtin_amdgcn_readfirstlane(tq.off) : 0;
+        const int ns_n = FRAME ? __builtin_amdgcn_readfirstlane(tq.ns) : 0;
+        const double fd_n = FRAME ? __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(tq.fd)), __builtin_amdgcn_readfirstlane(__double2loint(tq.fd))) : 0.0;
+        if (!FRAME) fetch(sg + gridDim.x, fn, kn, 0, pre, room_pre);   // stream mode: nothing else is loaded, the prefetch goes out first
         bool live = true;
         if (FRAME) {
-            if (p.nsym_frame && k >= p.nsym_frame[f]) live = false; // fewer symbols in this frame: nothing is written (workgroup-uniform)
+            if (k >= ns_cur) live = false; // fewer symbols in this frame: nothing is written (workgroup-uniform)
             if (!live) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
             } else if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50); phase reduced in f64
-                const double turns = p.f_delta[f] * 0.15915494309189533577;
+                const double turns = fd_cur * 0.15915494309189533577;
                 cf ph = cfo_phasor(turns, (long long)(p.first_symbol + k) * S + CP + col + 64 * t);
                 const cf st = cfo_phasor(turns, 512);
 #pragma unroll
@@ -955,6 +985,16 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
         __syncthreads(); // T complete; the PREVIOUS symbol's image complete (two barriers per symbol, not three: see below)
         if (pending) flush(pending); // ... so it leaves for HBM here, cleared for this symbol's fields, which are written after the next barrier
         pending = mine;
+        // FRAME: this symbol's channel is requested here and used behind stage B; only THEN does the next symbol's prefetch go out (its
+        // registers are free while the channel's are live: no register more than before) -- requested at its use the channel came in four
+        // serialized round trips, requested behind the prefetch its wait would drain the prefetch
+        cf hkv[8];
+        if (FRAME) {
+            const cf *h = p.hk ? p.hk + f * p.hk_stride + col : p.tw;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hkv[q] = h[64 * (t + 8 * q)];
+            __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler sinks these loads to their use, behind stage B: a round trip in the open)
+        }
         // ---- stage B: FFT64 over b for row c = col
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = T[col * TS + (t ^ (col & 6)) + 8 * m]; // (t + 8 m) ^ s = (t ^ s) + 8 m for s < 8: offsets stay immediates
@@ -971,12 +1011,18 @@ __global__ __launch_bounds__(512, 4) void k_demod4096(Big4096Params p) { // 4 wa
             const cf *h = p.hk + f * p.hk_stride;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const cf hh = h[col + 64 * (t + 8 * q)];
+                const cf hh = FRAME ? hkv[q] : h[col + 64 * (t + 8 * q)];
                 const float rn = __builtin_amdgcn_rcpf(hh.x * hh.x + hh.y * hh.y);
                 const cf e = cmulc(v[q], hh);
                 v[q] = make_float2(e.x * rn, e.y * rn);
             }
         }
+        if (FRAME) {   // the next symbol's samples from the start offset that arrived with this symbol's, then the scalars of the one after
+            fetch(sg + gridDim.x, fn, kn, off_n, pre, room_pre);
+            tq = load_scalars(sg + 2 * (long long)gridDim.x < p.total, f2);
+        }
+        f0 = fn; k0 = kn; fn = f2; kn = k2; advance(f2, k2);
+        ns_cur = ns_n; fd_cur = fd_n;
         cf rot = make_float2(1.f, 0.f);
         if (GUARD) { // decode_block (src/receiver.rs:106-145): mean angle of the 4 x 64 pilots, rotate by -phase
             // pilot classes 6, 25, 39, 58 = (t, q) = (6, 0), (1, 3), (7, 4), (2, 7); other lanes feed (1, 0) -> angle 0

@@ -216,11 +216,25 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
     // synchronous): out-of-range elements read the twiddle table instead and are zeroed when they leave the prefetch registers.
     // room = samples from this lane's first one to the end of the capture (FRAME), 0 past the batch.
     auto elem = [&](int e) -> int { return R >= 8 ? 64 * (u + Q * e) : 64 * (e % R) + LPS * (e / R); }; // stage-A input e, relative to the lane's first sample
-    auto fetch = [&](long long sg, cf *dst, int &room) {
+    // FRAME: the per-frame scalars (trimmed start, live-symbol count, CFO) of a step are REQUESTED two steps ahead and taken one step
+    // ahead (FS t2 -> s1): read where they were used -- offset, then the samples; the symbol count; the CFO; the channel, one after the
+    // other, each under its own condition -- every one of them was followed by s_waitcnt vmcnt(0), i.e. four serialized round trips to
+    // memory per step with the sample prefetch drained by the first (round-5 ISA scan; the stream mode of this kernel has none of them
+    // and ran twice as fast per symbol).  All loads are unconditional, from addresses that are always mapped.
+    struct FS { int off, ns; double fd; };
+    auto load_scalars = [&](bool in, long long fr_) -> FS {
+        const long long fr = in ? fr_ : 0;
+        FS r;
+        r.off = p.offset ? p.offset[fr] : 0;
+        r.ns = p.nsym_frame ? p.nsym_frame[fr] : p.syms_per_frame;
+        r.fd = p.f_delta ? p.f_delta[fr] : 0.0;
+        return r;
+    };
+    auto fetch = [&](long long sg, long long fr_, int kk, long long off_, cf *dst, int &room) {
         const bool in = sg < p.total;
-        const long long fr = in ? fn : 0;
-        const long long off = FRAME && p.offset ? p.offset[fr] : 0;
-        const long long n0 = off + (long long)(p.first_symbol + kn) * S + CP + colA; // first sample of this lane, inside the frame
+        const long long fr = in ? fr_ : 0;
+        const long long off = FRAME ? off_ : 0;
+        const long long n0 = off + (long long)(p.first_symbol + kk) * S + CP + colA; // first sample of this lane, inside the frame
         const cf *src = p.in + fr * p.frame_stride + n0;
         long long rm = FRAME ? p.frame_len - n0 : (long long)N;
         rm = in ? rm : 0;
@@ -240,27 +254,49 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
     for (int i = l; i < IMG_DW; i += LPS) myimg[i] = 0u;
     cf pre[8];
     int room_pre = 0;
-    fetch((long long)blockIdx.x * G + g, pre, room_pre);
     unsigned *pending = nullptr;
     const long long stride = (long long)gridDim.x * G;
+    auto advance = [&](long long &ff, int &kk) { ff += p.step_f; kk += p.step_k; if (kk >= p.syms_per_frame) { kk -= p.syms_per_frame; ++ff; } };
+    // positions of this lane's symbol: now (f0, k0), one step ahead (fn, kn: the sample prefetch), two ahead (f2, k2: the scalar prefetch)
+    long long f0 = fn, f2; int k0 = kn, k2;
+    advance(fn, kn);
+    f2 = fn; k2 = kn; advance(f2, k2);
+    const long long sg_first = (long long)blockIdx.x * G + g;
+    FS tq = FS{0, 0, 0.0};                          // scalars of the step one ahead, in flight since the step before
+    int ns_cur = 0; double fd_cur = 0.0;            // of the step being consumed
+    {
+        FS s0 = FS{0, 0, 0.0};
+        if (FRAME) s0 = load_scalars(sg_first < p.total, f0);
+        fetch(sg_first, f0, k0, s0.off, pre, room_pre);
+        ns_cur = s0.ns; fd_cur = s0.fd;
+        if (FRAME) tq = load_scalars(sg_first + stride < p.total, fn);
+    }
 
     for (long long base = (long long)blockIdx.x * G; base < p.total; base += stride) {
         const long long sg = base + g;
-        const long long f = fn; const int k = kn;
-        fn += p.step_f; kn += p.step_k;
-        if (kn >= p.syms_per_frame) { kn -= p.syms_per_frame; ++fn; }
+        const long long f = f0; const int k = k0;
         cf v[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = (!FRAME || elem(m) < room_pre) ? pre[m] : make_float2(0.f, 0.f);
-        fetch(sg + stride, pre, room_pre);
+        const FS sn = tq;                            // requested a step ago, behind that step's samples: here by now
+        // FRAME: the channel of THIS step's frame goes out first (its use, behind stage B, then waits for nothing younger), then the next
+        // step's samples from the start offset that has just arrived, then the scalars of the step after that
+        cf hkv[8];
+        if (FRAME) {
+            const cf *h = p.hk ? p.hk + (sg < p.total ? f : 0) * p.hk_stride + cB : p.tw;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hkv[q] = h[R * (t + 8 * q)];
+        }
+        fetch(sg + stride, fn, kn, sn.off, pre, room_pre);
+        if (FRAME) tq = load_scalars(sg + 2 * stride < p.total, f2);
         bool live = sg < p.total;
         if (FRAME) {
-            if (live && p.nsym_frame && k >= p.nsym_frame[f]) live = false; // fewer symbols in this frame (short capture / failed sync): nothing is written
+            if (live && k >= ns_cur) live = false; // fewer symbols in this frame (short capture / failed sync): nothing is written
             if (!live) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
             } else if (p.f_delta) { // CFO derotation, sample ids count from the trimmed start (receiver.rs:44-50); phase reduced in f64
-                const double turns = p.f_delta[f] * 0.15915494309189533577; // 1 / (2 pi)
+                const double turns = fd_cur * 0.15915494309189533577; // 1 / (2 pi)
                 const long long n0 = (long long)(p.first_symbol + k) * S + CP + colA;
                 if (R >= 8) {
                     cf ph = cfo_phasor(turns, n0 + 64 * u);
@@ -278,6 +314,9 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
                 }
             }
         }
+        // rotate the pipeline: positions move up one step, the next step's symbol count and CFO are kept for it
+        f0 = fn; k0 = kn; fn = f2; kn = k2; advance(f2, k2);
+        ns_cur = sn.ns; fd_cur = sn.fd;
         unsigned *const mine = live ? reinterpret_cast<unsigned *>(p.out + f * p.out_stride + (long long)k * nbytes) : nullptr;
         // ---- stage A, twiddle, transpose
         stage_a<R, false>(v, tA, u);
@@ -299,7 +338,7 @@ __global__ __launch_bounds__(256, Mid<R>::OCC_RX - (FRAME ? 1 : 0)) void k_demod
             const cf *h = p.hk + f * p.hk_stride;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const cf hh = h[cB + R * (t + 8 * q)];
+                const cf hh = FRAME ? hkv[q] : h[cB + R * (t + 8 * q)];
                 const float rn = __builtin_amdgcn_rcpf(hh.x * hh.x + hh.y * hh.y);
                 const cf e = cmulc(v[q], hh);
                 v[q] = make_float2(e.x * rn, e.y * rn);
