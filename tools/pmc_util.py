@@ -5,7 +5,7 @@ quad-cycle = 4 cycles, f64 ones for two: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU sho
 import collections, sys
 d = collections.defaultdict(dict)
 for line in open(sys.argv[1]):
-    name, ctr, calls, mean, mx = line.rstrip("\n").split("\t")
+    name, ctr, calls, mean, mx = line.rstrip("\n").split("\t")[:5]
     d[name.replace("void ofdm::", "").replace("ofdm::", "")][ctr] = float(mx.split("=")[1])   # the largest call (list-mode launches run near-empty)
 print("kernel\tvalu_util\tquad_cycles_per_valu_inst\tlds_util\tlds_bank_conflict_share\twait_share_of_wave_cycles")
 for k, c in sorted(d.items()):

@@ -12,12 +12,12 @@ OUT="$PWD/gpurun_out/prof"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH_ARGS=${BENCH_ARGS:-}
 if [ -z "$SKIP_BENCH" ]; then
-timeout -k 10 900 python3 bench.py $BENCH_ARGS > "$OUT/${ROUND}_bench.json" 2> "$OUT/${ROUND}_bench.err" || exit 1
+timeout -k 10 900 python3 bench.py --detail "$OUT/${ROUND}_bench_detail.json" $BENCH_ARGS > "$OUT/${ROUND}_bench.json" 2> "$OUT/${ROUND}_bench.err" || exit 1
 echo "bench done"
 # (--no-host: the host-buffer blocks launch k_demod64 / the decode chain on small chunks; without them k_demod64's average in this
 #  trace is the average of the timed headline configuration only)
 rm -rf /tmp/prof_kt
-( cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 "$OLDPWD/bench.py" --no-host $BENCH_ARGS > "$OUT/${ROUND}_bench_under_rocprof.json" 2> "$OUT/${ROUND}_rocprof_kt.err" ) || exit 2
+( cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 "$OLDPWD/bench.py" --no-host --detail /tmp/bench_detail_under_rocprof.json $BENCH_ARGS > "$OUT/${ROUND}_bench_under_rocprof.json" 2> "$OUT/${ROUND}_rocprof_kt.err" ) || exit 2
 f=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1)
 test -n "$f" || exit 3
 ( head -1 "$f"; grep "ofdm::" "$f" ) > "$OUT/${ROUND}_bench_kernel_stats_ofdm_only.csv"
