@@ -119,9 +119,9 @@ int ofdm_use_own_stream(ofdm_ctx *ctx);
 int ofdm_synchronize(ofdm_ctx *ctx);
 int ofdm_last_hip_error(const ofdm_ctx *ctx); /* raw hipError_t of the last failing HIP call */
 /* Which kernels served the LAST stage-level / pipeline entry point on this context: the names of the kernels its launchers
- * really enqueued, in order, joined by '+' (e.g. "k_scb_chunks<contig>+k_scb_fine<5>+k_rx_prepare+k_rxframe1024+k_rx_finish").
- * Every shape-specialised launcher has a generic fallback (k_sym<...>) for requests outside its envelope -- unaligned or
- * oddly strided buffers, soft outputs -- with the same results; this call is how a caller (and the parity tests) tell which
+ * really enqueued, in order, joined by '+' (e.g. "k_sc_stream<regs>+k_rx_prepare+k_rxframe1024<finish>").
+ * Every shape-specialised launcher has a generic fallback (k_sym<...>) for requests outside its envelope -- output rows that are not
+ * 4- / 16-byte aligned, soft outputs -- with the same results (captures need only their natural 8-byte alignment, any row stride); this call is how a caller (and the parity tests) tell which
  * one ran.  Returns the full length of the string (like snprintf), buf receives at most n - 1 characters. Host call. */
 int ofdm_last_dispatch(const ofdm_ctx *ctx, char *buf, size_t n);
 /* Per-context knobs and counters.  The library reads NO environment variable.  Keys a host legitimately needs:
