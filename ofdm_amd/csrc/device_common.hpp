@@ -430,13 +430,6 @@ __device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigne
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
-// One dword per lane by LDS-DMA from a PER-LANE address: lane i's dword lands at lds_byte_addr + 4 i.  No VGPR receives data, so a
-// value requested far ahead costs no register while it is in flight (k_rxframe1024's per-frame scalars).
-__device__ __forceinline__ void glds4v(const void *src, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_byte_addr) : "memory");
-}
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char *)p);
 }

@@ -314,22 +314,12 @@ __global__ __launch_bounds__(256, (MODE == 0 && GUARD) ? 4 : 3) void k_rxframe64
         }
     };
     fetch_scalars((long long)blockIdx.x * 4 + wave);
-    // The next frame's scalars leave their VGPRs (-> SGPRs) inside the frame body, BEFORE the last group's bytes are stored: taken at the
-    // top of the next iteration their wait (vmcnt(0): loads and stores share the counter) also waited for those stores to be acknowledged.
-    bool have_nx = false;
-    int ns_nx = 0, off_nx = 0, fdh_nx = 0, fdl_nx = 0;
-    auto take_scalars = [&]() {
-        ns_nx = __builtin_amdgcn_readfirstlane(ns_v); off_nx = __builtin_amdgcn_readfirstlane(off_v);
-        fdh_nx = __builtin_amdgcn_readfirstlane(__double2hiint(fd_v)); fdl_nx = __builtin_amdgcn_readfirstlane(__double2loint(fd_v));
-    };
     for (long long item = (long long)blockIdx.x * 4 + wave; item < n_items; item += istep) {
         const long long f = f_n;
-        if (!have_nx) take_scalars();   // the first frame, and behind a frame that was skipped or left to the cut-body launch
-        have_nx = false;
-        const int ns = ns_nx;
-        const long long off = off_nx;
-        const double turns = __hiloint2double(fdh_nx, fdl_nx) * 0.15915494309189533577;
-        fetch_scalars(item + istep);   // in flight until the frame body (or the next iteration) takes them
+        const int ns = __builtin_amdgcn_readfirstlane(ns_v);
+        const long long off = __builtin_amdgcn_readfirstlane(off_v);
+        const double turns = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(fd_v)), __builtin_amdgcn_readfirstlane(__double2loint(fd_v))) * 0.15915494309189533577;
+        fetch_scalars(item + istep);   // in flight until the next iteration reads them
         if (ns <= 0) { if (p.final_out && lane == 0) p.final_len[f] = 0; continue; } // wave-uniform
         const cf st = cfo_phasor(turns, 8);
         int keep = 0; // fused finish: bytes of this frame's output (known once the first group is demodulated)
@@ -457,7 +447,6 @@ __global__ __launch_bounds__(256, (MODE == 0 && GUARD) ? 4 : 3) void k_rxframe64
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = vn[m];
             zm = zn;
-            if (k0 + 8 >= ns) { take_scalars(); have_nx = true; }   // (every load issued so far has landed: the copies above waited for the youngest)
             const int ndw = (count * SYM_BYTES + 3) / 4;   // (6-byte symbols: an odd count ends in half a dword; its upper half is zero in the image and lies inside the row)
             if (p.final_out) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the image is complete

@@ -104,47 +104,22 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
         bo8[q] = carrier_class64(d, GUARD) == 0 ? ((GUARD ? data_classes_below64(d) : d) * 16 + row) * BPS : -1;
     }
 
-    // Per-frame scalars (live symbols, trimmed start, CFO).  Read where a frame is opened -- right behind the DMA of the previous frame's
-    // last item -- their wait (vmcnt(0): three vector loads, values needed at once) drained that DMA: once per frame the workgroup sat out
-    // a memory round trip with nothing in flight behind it (round-5 ISA scan).  They are now REQUESTED A FRAME AHEAD by LDS-DMA into a
-    // two-entry table (global_load_lds_dword from per-lane addresses: no register holds them while in flight, and the kernel has none to
-    // spare) and read from LDS when the frame is opened; the item loop's own waits and barriers lie in between (a frame has at least six
-    // items).  A frame the table does not hold (the first one, the one behind a skipped frame) is loaded in place as before.
-    __shared__ unsigned sctab[2][64];
-    long long sc_f = -1;      // the frame whose scalars were requested into sctab[sc_par]
-    int sc_par = 0;
+    // Per-frame scalars: the three loads of a frame go out together and are waited for once (as wave-uniform scalar values each
+    // would be moved to SGPRs, and waited for, right where it is issued: three dependent round trips to HBM per frame).
     int vzero = 0;
-    asm volatile("" : "+v"(vzero));   // a VGPR zero the compiler cannot fold: keeps the in-place loads per-lane
-    auto request_scalars = [&](long long f2) {
-        sc_par ^= 1;
-        sc_f = f2;
-        if (f2 >= p.n_frames || wave != 0) return;     // (wave-uniform)
-        const void *a = p.nsym + f2;                     // lanes >= 4 copy the symbol count once more (harmless: the table row has 64 dwords)
-        if (lane == 1 && p.offset) a = p.offset + f2;
-        if (lane == 2 && p.f_delta) a = p.f_delta + f2;
-        if (lane == 3 && p.f_delta) a = reinterpret_cast<const unsigned *>(p.f_delta + f2) + 1;
-        glds4v(a, lds_addr(&sctab[sc_par][0]));
-    };
+    asm volatile("" : "+v"(vzero));   // a VGPR zero the compiler cannot fold: keeps the loads per-lane
     auto open_frame = [&](Cur &c, long long f) {
         for (;;) {
             c.f = f; c.step = -5; c.rel = 0; c.ns = 0; c.turns = 0.0;
             if (f >= p.n_frames) return;
-            if (f == sc_f) {
-                const unsigned *row = sctab[sc_par];
-                const unsigned w0 = row[0], w1 = row[1], w2 = row[2], w3 = row[3];
-                c.ns = __builtin_amdgcn_readfirstlane((int)w0);
-                c.rel = p.offset ? (long long)__builtin_amdgcn_readfirstlane((int)w1) : 0;
-                c.turns = p.f_delta ? __hiloint2double(__builtin_amdgcn_readfirstlane((int)w3), __builtin_amdgcn_readfirstlane((int)w2)) * 0.15915494309189533577 : 0.0;
-            } else {
-                const long long fi = f + vzero;
-                const int ns_v = p.nsym[fi];
-                const int off_v = p.offset ? p.offset[fi] : 0;
-                const double fd_v = p.f_delta ? p.f_delta[fi] : 0.0;
-                c.ns = __builtin_amdgcn_readfirstlane(ns_v);
-                c.rel = __builtin_amdgcn_readfirstlane(off_v);
-                c.turns = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(fd_v)), __builtin_amdgcn_readfirstlane(__double2loint(fd_v))) * 0.15915494309189533577;
-            }
-            if (c.ns > 0) { request_scalars(f + gridDim.x); return; }
+            const long long fi = f + vzero;
+            const int ns_v = p.nsym[fi];
+            const int off_v = p.offset ? p.offset[fi] : 0;
+            const double fd_v = p.f_delta ? p.f_delta[fi] : 0.0;
+            c.ns = __builtin_amdgcn_readfirstlane(ns_v);
+            c.rel = __builtin_amdgcn_readfirstlane(off_v);
+            c.turns = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(fd_v)), __builtin_amdgcn_readfirstlane(__double2loint(fd_v))) * 0.15915494309189533577;
+            if (c.ns > 0) return;
             if (fused && tid == 0) p.final_len[f] = 0;   // no sync / short capture: nothing decoded (every skipped frame is visited exactly once)
             f += gridDim.x;
         }
@@ -366,7 +341,6 @@ __global__ __launch_bounds__(128, 3) void k_rxframe1024(RxFrame1024Params p) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) g[q] = make_float2(0.f, 0.f);
     }
-    wait_vm<0>();   // (a scalar request for a frame past the batch is never issued, but nothing may be in flight into LDS when the wave ends)
 }
 
 // Fused channel estimate + demod [+ finish] for N = 1024 frames.  hipErrorNotSupported => caller uses run_chest + run_demod.
