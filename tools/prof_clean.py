@@ -46,7 +46,13 @@ if which in ("sc_every_lag", "cfg3_chain", "cfg3_late"):
         ctx.set_tuning("sc_first_lags", 0)
         out["ms"] = timed(ctx, lambda: ctx.sc_correlate(x))
         disp = ctx.last_dispatch()
-        out["bytes_per_frame"] = span * 8 + 16                      # every lag is computed: the whole slot
+        # k_sc80 stops reading a slot once its decision is determined: slot bytes / time is a throughput, the roofline is taken on the
+        # bytes the decision requires, as in the chain blocks
+        d_all, _, _ = ctx.sc_correlate(x)
+        L, W = ctx.S, ctx.params.sync_window_reps * ctx.S
+        out["required_bytes_per_frame"] = bench_cfg3.required_sync_bytes(torch, d_all, span, W, L) / n
+        out["bytes_per_frame"] = out["required_bytes_per_frame"]
+        out["capture_throughput_of_hbm_peak"] = n * (span * 8 + 16) / (out["ms"] / 1e3) / 8e12
     else:
         out["ms"] = timed(ctx, lambda: ctx.decode_batch(x, max_symbols=16))
         disp = ctx.last_dispatch()
