@@ -604,13 +604,13 @@ struct MidTxFrameParams {
 
 // KEEP > 0: a round's symbols fit KEEP steps, so every lane KEEPS its KEEP x 8 points in registers while the round's maxima form and
 // the symbols are built ONCE (N = 128 / 256 / 512 frames of up to 16 / 16 / 16 data symbols); KEEP == 0: the two-pass scheme above.
+// (R <= 8, two-pass / optimistic form: 117-128 VGPRs and, with the transpose slabs folded into T, 23 KB of LDS -> FOUR waves per SIMD)
 template <int R, bool GUARD, int KEEP>
-__global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
+__global__ __launch_bounds__(256, (R <= 8 && KEEP == 0) ? 4 : 3) void k_txframe_mid(MidTxFrameParams p) {
     typedef Mid<R> M;
     constexpr int N = M::N, S = M::S, CP = M::CP, LPS = M::LPS, G = M::G, Q = M::Q, TS = M::TS;
     constexpr int ND = GUARD ? 48 * R : N;
     constexpr int SB_DW = 16 * R + 2;
-    __shared__ cf slab_all[4 * M::SLAB];
     __shared__ __align__(16) cf T[32 * TS];
     __shared__ unsigned sbw_all[G * SB_DW];
     __shared__ cf ptab[256];
@@ -623,7 +623,9 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
     const int colA = R >= 8 ? l / Q : l;
     const int t = tid & 7, rs = tid >> 3;
     const int cB = M::row_of_slot(rs % R);
-    cf *buf = slab_all + wave * M::SLAB + (lane >> 3) * 72;
+    // the FFT64 transposes of stage B run IN PLACE in the eight-lane group's own row of T (the row it has just read its inputs from: nobody
+    // else reads it, and the in-order LDS pipe keeps the reads ahead of the writes) -- as k_rxframe1024 does: no separate slabs, 18 KB less LDS
+    cf *buf = T + rs * TS;
     const int wr = swz(8 * t);
     unsigned *sbw = sbw_all + g * SB_DW;
     cf *Tsym = T + g * R * TS;
@@ -705,6 +707,7 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
         symbol_sync<LPS>();
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = T[rs * TS + t + 8 * m];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the row reads above precede stage B's in-place writes
         stage_b<true>(v, buf, t, wr, w);
         symbol_sync<LPS>(); // T and the byte window are free again
     };
@@ -754,9 +757,10 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
         }
     };
     auto note_max = [&](bool valid, int fl, const cf *v) {
-        float mine = 0.f;
+        float mine = 0.f;   // max first, ONE scaling behind it (x -> x / N is monotone: the same bits as scaling every sample), three-operand maxima
 #pragma unroll
-        for (int q = 0; q < 8; ++q) mine = fmaxf(mine, fmaxf(v[q].x, v[q].y) * (1.0f / N));
+        for (int q = 0; q < 8; ++q) mine = __builtin_fmaxf(mine, __builtin_fmaxf(v[q].x, v[q].y));
+        mine *= 1.0f / N;
         constexpr int WL = LPS < 64 ? LPS : 64;
 #pragma unroll
         for (int sh = WL / 2; sh >= 1; sh >>= 1) mine = fmaxf(mine, __shfl_xor(mine, sh, 64));
@@ -868,11 +872,9 @@ __global__ __launch_bounds__(256, 3) void k_txframe_mid(MidTxFrameParams p) {
             if (pass == 1) {
                 lds_barrier();       // every maximum of the round is final
                 emit_headers(f0);
-                if (opt) {
-                    bool redo = false;
-                    for (int fl = 0; fl < p.fpw; ++fl) redo |= __uint_as_float(fmax[fl]) > p.header_max;
-                    if (!redo) break;
-                }
+                bool redo = false;
+                for (int fl = 0; fl < p.fpw; ++fl) redo |= __uint_as_float(fmax[fl]) > p.header_max;
+                if (opt && !redo) break;
             }
             for (int step = 0; step < steps; ++step) {
                 long long f; int fl, k; bool valid;
@@ -911,7 +913,9 @@ template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, h
     // maximum is known; otherwise frames per round: the count (<= 8, <= 32 slots' worth) that wastes the fewest symbol slots of
     // the last step, and every symbol is built twice
     const int steps1 = (p.D + G - 1) / G;
-    const int keep = (steps1 <= keep_max && steps1 <= 1) ? 1 : 0;   // KEEP = 2 / 4 instantiate the symbol builder 2 / 4 times: 18-170 spilled registers, not built
+    // (R <= 4: the optimistic two-pass form runs at four waves per SIMD and is as fast or faster -- tools/lab/enc_keep_ab.py: N = 128, D = 8:
+    //  0.65 against 0.575 of the one-write roofline; N = 256, D = 8: 0.64 against 0.60; from R = 8 on the kept form is 0-3 % ahead)
+    const int keep = (steps1 <= keep_max && steps1 <= 1 && R >= 8) ? 1 : 0;   // KEEP = 2 / 4 instantiate the symbol builder 2 / 4 times: 18-170 spilled registers, not built
     if (keep) p.fpw = 1;
     else {
         int best = 1; double waste = 2.0;
@@ -923,7 +927,7 @@ template <int R> hipError_t launch_txframe_mid(MidTxFrameParams p, bool guard, h
         p.fpw = best;
     }
     const long long rounds = (p.n_frames + p.fpw - 1) / p.fpw;
-    const dim3 grid((unsigned)mid_grid(rounds, num_cu, 3, cap)); // built for 3 waves per SIMD: the twice-inlined symbol builder spills at 4
+    const dim3 grid((unsigned)mid_grid(rounds, num_cu, (R <= 8 && !keep && !rewrite) ? 4 : 3, cap)); // waves per SIMD the instantiation is built for
     if (keep) launch_txframe_mid_k<R, 1>(p, guard, grid, st);
     else if (rewrite) launch_txframe_mid_k<R, -1>(p, guard, grid, st);
     else launch_txframe_mid_k<R, 0>(p, guard, grid, st);
@@ -1004,8 +1008,9 @@ hipError_t run_txframe_mid(int n_fft, const SymParams &sp, const float2 *header,
     const long long cap = tu.grid_cap;
     const int keep_max = tu.txframe_keep_steps;   // 0 = always build twice (A/B)
     const int G = 32 / R, steps1 = (p.D + G - 1) / G;
-    const bool rewrite = tu.txframe_rewrite != 0 && !(steps1 <= keep_max && steps1 <= 1);
-    trace_add(sp.trace, (steps1 <= keep_max && steps1 <= 1) ? "k_txframe_mid<once>" : rewrite ? "k_txframe_mid<rewrite>" : "k_txframe_mid");
+    const bool once = steps1 <= keep_max && steps1 <= 1 && R >= 8;   // (launch_txframe_mid's condition)
+    const bool rewrite = tu.txframe_rewrite != 0 && !once;
+    trace_add(sp.trace, once ? "k_txframe_mid<once>" : rewrite ? "k_txframe_mid<rewrite>" : "k_txframe_mid");
     switch (R) {
     case 1: return launch_txframe_mid<1>(p, sp.guard != 0, st, num_cu, cap, keep_max, rewrite);
     case 2: return launch_txframe_mid<2>(p, sp.guard != 0, st, num_cu, cap, keep_max, rewrite);

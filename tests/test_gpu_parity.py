@@ -831,7 +831,7 @@ def test_tx_encode_mid_frames(api, orc, n, mod, guard, nbytes):
     frames = host(ctx.encode_batch(torch.from_numpy(pay).to(ctx.device), lens=torch.from_numpy(lens)))
     S, D = n + n // 4, ctx.data_symbols(nbytes)
     # frames whose data symbols fit ONE workgroup step of the R x 64 kernel (D <= 32 / R) are built once, the others twice
-    mid = "k_txframe_mid<once>" if D <= 32 // (n // 64) else "k_txframe_mid"
+    mid = "k_txframe_mid<once>" if n >= 512 and D <= 32 // (n // 64) else "k_txframe_mid"   # (N <= 256: the optimistic form at four waves per SIMD is faster)
     assert ctx.last_dispatch() == ("k_txframe4096" if n == 4096 else mid if n > 64 or D > 56 else "k_txframe64")
     assert frames.shape == (nfr, (10 + D) * S)
     for f in range(nfr):
