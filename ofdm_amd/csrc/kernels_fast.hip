@@ -1429,9 +1429,10 @@ __global__ __launch_bounds__(512, 4) void k_txframe4096(TxFrame4096Params p) {
                 bfly8<true>(v);
                 // v[q] = N x[col + 64 (t + 8 q)]
                 if (pass == 0) {
-                    float mine = 0.f;
+                    float mine = 0.f;   // max first, one scaling behind it (x -> x / N is monotone: the same bits), three-operand maxima
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) mine = fmaxf(mine, fmaxf(v[q].x, v[q].y) * (1.0f / N));
+                    for (int q = 0; q < 8; ++q) mine = __builtin_fmaxf(mine, __builtin_fmaxf(v[q].x, v[q].y));
+                    mine *= 1.0f / N;
 #pragma unroll
                     for (int sh = 32; sh >= 1; sh >>= 1) mine = fmaxf(mine, __shfl_xor(mine, sh, 64));
                     if (lane == 0) atomicMax(fmax, __float_as_uint(mine));
