@@ -38,6 +38,7 @@ struct Tuning {
     int demod64_wg_per_cu = 0;     // k_demod64: persistent workgroups per CU (0 = from the occupancy API)
     int demod64_burst = 16;        // k_demod64: groups per store burst (16 / 8 / 4; 1 = no bursts)
     int demod64_narrow_stores = 0; // k_demod64: 4-byte instead of 16-byte image stores
+    int demod64_store_policy = 0;  // k_demod64: cache-policy bits on the 16-byte image stores (0 default, 1 nt, 2 sc1, 3 sc0 sc1): the output-buffer populations probe
     int scb_two_segments = 0;      // k_scb_chunks: two-segment staging also for L <= 1280
     int scb_big_tiles = 0;         // k_scb_fine: 1280-lag tiles / 128 threads
     int debug_demod64 = 0, debug_sc = 0, debug_tx = 0; // profile build only (kProfile)
@@ -120,6 +121,7 @@ struct Fast64Params {
     long long f0 = 0, blk_df = 0, wave_df = 0, step_df = 0; // frame index bookkeeping without division
     int k0 = 0, blk_dk = 0, wave_dk = 0, step_dk = 0;
     int wide_stores = 0;        // the packed image leaves with 16-byte stores (aligned output)
+    int store_policy = 0;       // lab key demod64_store_policy: cache-policy bits on the image stores (0 default, 1 nt, 2 sc1, 3 sc0 sc1)
     int debug = 0;              // profiling aid (OFDM_DEMOD64_DEBUG): 1 no stores, 2 no packing either, 3 loads + first butterfly only
 };
 hipError_t run_demod64_fast(const SymParams &p, hipStream_t st, int num_cu);

@@ -168,6 +168,17 @@ __global__ __launch_bounds__(256, 4) void k_demod64(Fast64Params p) {
         if (kProfile && p.debug == 4) dst = reinterpret_cast<unsigned *>(p.out) + (blockIdx.x & 255) * 4 * BURST * REGION_DW + wave * BURST * REGION_DW; // L2-resident window
         if (kProfile && p.debug == 5) { for (int i = lane; i < ndw; i += 64) __builtin_nontemporal_store(img0[i], dst + i); return; }
         if ((REGION_DW % 4) == 0 && p.wide_stores) { // 16 bytes per lane
+            if (p.store_policy) {   // lab key demod64_store_policy: 1 = nt, 2 = sc1, 3 = sc0 sc1 on the image stores (the output-buffer populations)
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                for (int i = lane; i < ndw / 4; i += 64) {
+                    const v4u val = reinterpret_cast<const v4u *>(img0)[i];
+                    uint4 *a = reinterpret_cast<uint4 *>(dst) + i;
+                    if (p.store_policy == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(a), "v"(val) : "memory");
+                    else if (p.store_policy == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(a), "v"(val) : "memory");
+                    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a), "v"(val) : "memory");
+                }
+                return;
+            }
             for (int i = lane; i < ndw / 4; i += 64) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(img0)[i];
         } else for (int i = lane; i < ndw; i += 64) dst[i] = img0[i];
     };
@@ -1515,6 +1526,7 @@ template <int BPS, bool GUARD, bool HK> static hipError_t launch_demod64(Fast64P
     p.debug = kProfile ? tu.debug_demod64 : 0;
     constexpr int region_bytes = (GUARD ? 48 : 64) * BPS;
     {   // 16-byte stores need 16-byte aligned group regions: base, frame stride and the 8-symbol region itself
+        p.store_policy = tu.demod64_store_policy;
         p.wide_stores = !tu.demod64_narrow_stores && region_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (p.out_stride & 15) == 0;
     }
     // burst mode (config-2 shape only: the template is instantiated once): 4 groups per step, whole-line stores

@@ -14,7 +14,8 @@
 //     sc80_depth          k_sc80: steps between the last read of a ring piece and its refill (2: 7 KiB in flight per wavefront, 1: 9-10)
 //     sc_wg_per_cu, sc_first_lags, sc128_one_wave                     k_sc_cf (the filter pair): workgroups per CU, lags of the first
 //                         launch (0 = one launch), one wavefront per frame in the 128-chunk kernel
-//     demod64_wg_per_cu, demod64_burst (16 / 8 / 4 / 1), demod64_narrow_stores   k_demod64
+//     demod64_wg_per_cu, demod64_burst (16 / 8 / 4 / 1), demod64_narrow_stores,  k_demod64
+//     demod64_store_policy (0, 1 nt, 2 sc1, 3 sc0 sc1)
 //     tx_waves, txframe_keep_steps, txframe_rewrite,                  k_txframe64 / k_txframe_mid / k_txframe4096
 //     no_txframe_optimistic
 //     scb_two_segments, scb_big_tiles                                 k_scb_chunks / k_scb_fine
@@ -44,6 +45,7 @@ OFDM_TUNE_KEY("sc128_one_wave", sc128_one_wave, false)
 OFDM_TUNE_KEY("demod64_wg_per_cu", demod64_wg_per_cu, false)
 OFDM_TUNE_KEY("demod64_burst", demod64_burst, false)
 OFDM_TUNE_KEY("demod64_narrow_stores", demod64_narrow_stores, false)
+OFDM_TUNE_KEY("demod64_store_policy", demod64_store_policy, false)
 OFDM_TUNE_KEY("scb_two_segments", scb_two_segments, false)
 OFDM_TUNE_KEY("scb_big_tiles", scb_big_tiles, false)
 OFDM_TUNE_KEY("debug_demod64", debug_demod64, true)
